@@ -1,0 +1,450 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's precompile logic
+ * (sean-sn/blst_eip2537, src/eip2537.c) on the from-scratch arithmetic in ora_field.h / ora_ec.h.
+ *
+ * PARITY UNPINNED: the arithmetic library the reference calls (supranational/blst, unpinned,
+ * cloned by build.sh:3-5) is not under /root/reference and the reference's known-answer files
+ * (build.sh:13-52) are absent, so no golden vector of the reference pins these outputs.  What
+ * pins them instead is listed in DESIGN.md ("Oracle").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Exported symbols are prefixed oracle_ so they can never satisfy the product's bls12_* ABI.
+ *
+ * Control flow restated (file:line of the reference):
+ *   fp_from_bytes / fp_to_bytes                  src/eip2537.c:263-317
+ *   decode/encode G1, Fp2, G2, scalar            src/eip2537.c:320-420
+ *   bls12_g1add / g1mul                          src/eip2537.c:434-524
+ *   bls12_g1multiexp dispatcher (1 / <=4 / else) src/eip2537.c:541-561
+ *   bls12_g1multiexp_naive                       src/eip2537.c:564-616
+ *   Bos-Coster heap + driver                     src/eip2537.c:57-205, 619-708
+ *   G2 clones                                    src/eip2537.c:208-259, 722-998
+ *   bls12_pairing                                src/eip2537.c:1020-1081
+ *   gas schedule                                 src/eip2537.c:1168-1271
+ */
+#include <stdlib.h>
+#include "ora_ec.h"
+
+enum {
+    ORA_SUCCESS = 0, ORA_POINT_NOT_ON_CURVE, ORA_POINT_NOT_IN_SUBGROUP, ORA_INVALID_ELEMENT,
+    ORA_ENCODING_ERROR, ORA_INVALID_LENGTH, ORA_EMPTY_INPUT, ORA_MEMORY_ERROR
+};
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ codec */
+/* returns -1 invalid, 0 zero, 1 non-zero (src/eip2537.c:263-309) */
+static int ora_fp_from_bytes(fp *out, const uint8_t *in) {
+    uint8_t pad = 0;
+    for (int i = 0; i < 16; i++) pad |= in[i];
+    if (pad) return -1;
+    fp raw;
+    for (int limb = 0; limb < 6; limb++) {
+        uint64_t w = 0;
+        const uint8_t *src = in + 16 + (5 - limb) * 8;
+        for (int b = 0; b < 8; b++) w = (w << 8) | src[b];
+        raw.l[limb] = w;
+    }
+    /* value < p  <=>  raw - p borrows */
+    uint64_t borrow = 0, nz = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 d = (u128)raw.l[i] - ORA_P[i] - borrow;
+        borrow = (uint64_t)(d >> 64) & 1;
+        nz |= raw.l[i];
+    }
+    if (!borrow) return -1;
+    fp_to_mont(out, &raw);
+    return nz != 0;
+}
+static void ora_fp_to_bytes(uint8_t *out, const fp *a) {
+    fp raw;
+    fp_from_mont(&raw, a);
+    memset(out, 0, 16);
+    for (int limb = 0; limb < 6; limb++) {
+        uint64_t w = raw.l[limb];
+        uint8_t *dst = out + 16 + (5 - limb) * 8;
+        for (int b = 7; b >= 0; b--) { dst[b] = (uint8_t)w; w >>= 8; }
+    }
+}
+static int ora_decode_g1(g1_aff *out, const uint8_t *in) {
+    int sx = ora_fp_from_bytes(&out->x, in);
+    int sy = ora_fp_from_bytes(&out->y, in + 64);
+    if (sx < 0 || sy < 0) return ORA_INVALID_ELEMENT;
+    if (sx == 0 && sy == 0) return ORA_SUCCESS;
+    if (!g1_aff_on_curve(out)) return ORA_POINT_NOT_ON_CURVE;
+    return ORA_SUCCESS;
+}
+static void ora_encode_g1(uint8_t *out, const g1_aff *a) {
+    ora_fp_to_bytes(out, &a->x);
+    ora_fp_to_bytes(out + 64, &a->y);
+}
+static int ora_fp2_from_bytes(fp2 *out, const uint8_t *in) {
+    int s0 = ora_fp_from_bytes(&out->c0, in);
+    int s1 = ora_fp_from_bytes(&out->c1, in + 64);
+    if (s0 < 0 || s1 < 0) return -1;
+    return s0 | s1;
+}
+static void ora_fp2_to_bytes(uint8_t *out, const fp2 *a) {
+    ora_fp_to_bytes(out, &a->c0);
+    ora_fp_to_bytes(out + 64, &a->c1);
+}
+static int ora_decode_g2(g2_aff *out, const uint8_t *in) {
+    int sx = ora_fp2_from_bytes(&out->x, in);
+    int sy = ora_fp2_from_bytes(&out->y, in + 128);
+    if (sx < 0 || sy < 0) return ORA_INVALID_ELEMENT;
+    if (sx == 0 && sy == 0) return ORA_SUCCESS;
+    if (!g2_aff_on_curve(out)) return ORA_POINT_NOT_ON_CURVE;
+    return ORA_SUCCESS;
+}
+static void ora_encode_g2(uint8_t *out, const g2_aff *a) {
+    ora_fp2_to_bytes(out, &a->x);
+    ora_fp2_to_bytes(out + 128, &a->y);
+}
+/* 32 big-endian bytes -> 32 little-endian bytes; never fails, no reduction (:417-420) */
+static void ora_decode_scalar(uint8_t out_le[32], const uint8_t *in) {
+    for (int i = 0; i < 32; i++) out_le[i] = in[31 - i];
+}
+
+/* ------------------------------------------------------------------ Bos-Coster heap */
+typedef struct { uint64_t k[4]; uint32_t base; } ora_heap_item;
+
+static inline int sc_less(const uint64_t a[4], const uint64_t b[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] < b[i];
+    }
+    return 0;
+}
+static inline void sc_sub(uint64_t a[4], const uint64_t b[4]) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        a[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+}
+static inline int sc_bits(const uint64_t a[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i]) return 64 * (i + 1) - __builtin_clzll(a[i]);
+    }
+    return 0;
+}
+static inline void sc_to_le_bytes(uint8_t out[32], const uint64_t a[4]) {
+    for (int i = 0; i < 32; i++) out[i] = (uint8_t)(a[i / 8] >> (8 * (i % 8)));
+}
+/* move the hole at `pos` up towards `stop` while the parent is smaller than `item` */
+static void heap_bubble_up(ora_heap_item *h, int stop, int pos, const ora_heap_item *item) {
+    while (pos > stop) {
+        int parent = (pos - 1) >> 1;
+        if (!sc_less(h[parent].k, item->k)) break;
+        h[pos] = h[parent];
+        pos = parent;
+    }
+    h[pos] = *item;
+}
+/* restore the max-heap below `start`: walk the larger child down to a leaf, then bubble the
+ * displaced item back up (the bottom-up strategy of src/eip2537.c:126-144) */
+static void heap_fix_down(ora_heap_item *h, int size, int start) {
+    ora_heap_item item = h[start];
+    int pos = start, child = 2 * start + 1;
+    while (child < size) {
+        int right = child + 1;
+        if (right < size && !sc_less(h[right].k, h[child].k)) child = right;
+        h[pos] = h[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    heap_bubble_up(h, start, pos, &item);
+}
+static void heap_build(ora_heap_item *h, int size) {
+    for (int i = (size - 1) / 2; i >= 0; i--) heap_fix_down(h, size, i);
+}
+
+#define DEFINE_MSM(G, REC, PTB, OUTB, DECODE, ENCODE)                                              \
+/* one Bos-Coster step; returns 0 when the second-largest scalar is zero (:154-205) */             \
+static int G##_bc_step(G##_jac *side, G##_jac *bases, ora_heap_item *h, int size) {               \
+    ora_heap_item *second = &h[1];                                                                 \
+    if (size > 2 && sc_less(h[1].k, h[2].k)) second = &h[2];                                       \
+    int second_bits = sc_bits(second->k);                                                          \
+    if (second_bits == 0) return 0;                                                                \
+    int top_bits = sc_bits(h[0].k);                                                                \
+    if (top_bits - second_bits > 6) {                                                              \
+        uint8_t kb[32];                                                                            \
+        sc_to_le_bytes(kb, h[0].k);                                                                \
+        G##_jac *b = &bases[h[0].base];                                                            \
+        if (!G##_is_inf(side)) {                                                                   \
+            G##_mult(b, b, kb, top_bits);                                                          \
+            G##_add(side, side, b);                                                                \
+        } else {                                                                                   \
+            G##_mult(side, b, kb, top_bits);                                                       \
+        }                                                                                          \
+        memset(h[0].k, 0, sizeof h[0].k);                                                          \
+    } else {                                                                                       \
+        sc_sub(h[0].k, second->k);                                                                 \
+        G##_add(&bases[second->base], &bases[second->base], &bases[h[0].base]);                    \
+    }                                                                                              \
+    heap_fix_down(h, size, 0);                                                                     \
+    return 1;                                                                                      \
+}                                                                                                  \
+EXPORT int oracle_bls12_##G##mul(uint8_t *out, const uint8_t *in, size_t in_len) {                 \
+    if (in_len != REC) return ORA_INVALID_LENGTH;                                                  \
+    G##_aff a;                                                                                     \
+    int rc = DECODE(&a, in);                                                                       \
+    if (rc != ORA_SUCCESS) return rc;                                                              \
+    uint8_t k[32];                                                                                 \
+    ora_decode_scalar(k, in + PTB);                                                                \
+    G##_jac p;                                                                                     \
+    G##_from_affine(&p, &a);                                                                       \
+    G##_mult(&p, &p, k, 256);                                                                      \
+    G##_to_affine(&a, &p);                                                                         \
+    ENCODE(out, &a);                                                                               \
+    return ORA_SUCCESS;                                                                            \
+}                                                                                                  \
+EXPORT int oracle_bls12_##G##multiexp_naive(uint8_t *out, const uint8_t *in, size_t in_len) {      \
+    if (in_len == 0 || in_len % REC) return ORA_INVALID_LENGTH;                                    \
+    size_t n = in_len / REC;                                                                       \
+    G##_jac acc;                                                                                   \
+    G##_set_inf(&acc);                                                                             \
+    for (size_t i = 0; i < n; i++, in += REC) {                                                    \
+        G##_aff a;                                                                                 \
+        int rc = DECODE(&a, in);                                                                   \
+        if (rc != ORA_SUCCESS) return rc;                                                          \
+        uint8_t k[32];                                                                             \
+        ora_decode_scalar(k, in + PTB);                                                            \
+        G##_jac p;                                                                                 \
+        G##_from_affine(&p, &a);                                                                   \
+        G##_mult(&p, &p, k, 256);                                                                  \
+        G##_add(&acc, &acc, &p);                                                                   \
+    }                                                                                              \
+    G##_aff r;                                                                                     \
+    G##_to_affine(&r, &acc);                                                                       \
+    ENCODE(out, &r);                                                                               \
+    return ORA_SUCCESS;                                                                            \
+}                                                                                                  \
+EXPORT int oracle_bls12_##G##multiexp_bc(uint8_t *out, const uint8_t *in, size_t in_len) {         \
+    if (in_len == 0 || in_len % REC) return ORA_INVALID_LENGTH;                                    \
+    size_t n = in_len / REC;                                                                       \
+    G##_jac *bases = malloc(n * sizeof *bases);                                                    \
+    if (!bases) return ORA_MEMORY_ERROR;                                                           \
+    ora_heap_item *heap = malloc(n * sizeof *heap);                                                \
+    if (!heap) { free(bases); return ORA_MEMORY_ERROR; }                                           \
+    for (size_t i = 0; i < n; i++, in += REC) {                                                    \
+        G##_aff a;                                                                                 \
+        int rc = DECODE(&a, in);                                                                   \
+        if (rc != ORA_SUCCESS) { free(bases); free(heap); return rc; }                             \
+        G##_from_affine(&bases[i], &a);                                                            \
+        uint8_t k[32];                                                                             \
+        ora_decode_scalar(k, in + PTB);                                                            \
+        memcpy(heap[i].k, k, 32);                                                                  \
+        heap[i].base = (uint32_t)i;                                                                \
+    }                                                                                              \
+    heap_build(heap, (int)n);                                                                      \
+    G##_jac side, res;                                                                             \
+    G##_set_inf(&side);                                                                            \
+    if (n > 1) { while (G##_bc_step(&side, bases, heap, (int)n)) { } }                             \
+    uint8_t kb[32];                                                                                \
+    sc_to_le_bytes(kb, heap[0].k);                                                                 \
+    G##_mult(&res, &bases[heap[0].base], kb, sc_bits(heap[0].k));                                  \
+    if (!G##_is_inf(&side)) G##_add(&res, &res, &side);                                            \
+    G##_aff r;                                                                                     \
+    G##_to_affine(&r, &res);                                                                       \
+    ENCODE(out, &r);                                                                               \
+    free(bases);                                                                                   \
+    free(heap);                                                                                    \
+    return ORA_SUCCESS;                                                                            \
+}                                                                                                  \
+EXPORT int oracle_bls12_##G##multiexp(uint8_t *out, const uint8_t *in, size_t in_len) {            \
+    if (in_len == 0 || in_len % REC) return ORA_INVALID_LENGTH;                                    \
+    size_t n = in_len / REC;                                                                       \
+    if (n == 1) return oracle_bls12_##G##mul(out, in, in_len);                                     \
+    if (n <= 4) return oracle_bls12_##G##multiexp_naive(out, in, in_len);                          \
+    return oracle_bls12_##G##multiexp_bc(out, in, in_len);                                         \
+}                                                                                                  \
+EXPORT int oracle_bls12_##G##add(uint8_t *out, const uint8_t *in, size_t in_len) {                 \
+    if (in_len != 2 * PTB) return ORA_INVALID_LENGTH;                                              \
+    G##_aff a, b;                                                                                  \
+    int rc = DECODE(&a, in);                                                                       \
+    if (rc != ORA_SUCCESS) return rc;                                                              \
+    rc = DECODE(&b, in + PTB);                                                                     \
+    if (rc != ORA_SUCCESS) return rc;                                                              \
+    G##_jac p;                                                                                     \
+    G##_from_affine(&p, &a);                                                                       \
+    G##_add_affine(&p, &p, &b);                                                                    \
+    G##_to_affine(&a, &p);                                                                         \
+    ENCODE(out, &a);                                                                               \
+    return ORA_SUCCESS;                                                                            \
+}
+
+DEFINE_MSM(g1, 160, 128, 128, ora_decode_g1, ora_encode_g1)
+DEFINE_MSM(g2, 288, 256, 256, ora_decode_g2, ora_encode_g2)
+
+/* ------------------------------------------------------------------ pairing (:1020-1081) */
+EXPORT int oracle_bls12_pairing(uint8_t *out, const uint8_t *in, size_t in_len) {
+    if (in_len == 0 || in_len % 384) return ORA_INVALID_LENGTH;
+    size_t k = in_len / 384;
+    fp12 acc, cur;
+    fp12_one(&acc);
+    for (size_t i = 0; i < k; i++, in += 384) {
+        g1_aff p;
+        g2_aff q;
+        int rc = ora_decode_g1(&p, in);
+        if (rc != ORA_SUCCESS) return rc;
+        if (!g1_in_subgroup(&p)) return ORA_POINT_NOT_IN_SUBGROUP;
+        rc = ora_decode_g2(&q, in + 128);
+        if (rc != ORA_SUCCESS) return rc;
+        if (!g2_in_subgroup(&q)) return ORA_POINT_NOT_IN_SUBGROUP;
+        if (i > 0) {
+            ora_miller_loop(&cur, &q, &p);
+            fp12_mul(&acc, &acc, &cur);
+        } else {
+            ora_miller_loop(&acc, &q, &p);
+        }
+    }
+    ora_final_exp(&acc, &acc);
+    memset(out, 0, 32);
+    if (fp12_is_one(&acc)) out[31] = 1;
+    return ORA_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ gas (:1168-1271) */
+static const uint64_t ORA_DISCOUNT[128] = {
+    1200, 888, 764, 641, 594, 547, 500, 453, 438, 423, 408, 394, 379, 364, 349, 334,
+    330, 326, 322, 318, 314, 310, 306, 302, 298, 294, 289, 285, 281, 277, 273, 269,
+    268, 266, 265, 263, 262, 260, 259, 257, 256, 254, 253, 251, 250, 248, 247, 245,
+    244, 242, 241, 239, 238, 236, 235, 233, 232, 231, 229, 228, 226, 225, 223, 222,
+    221, 220, 219, 219, 218, 217, 216, 216, 215, 214, 213, 213, 212, 211, 211, 210,
+    209, 208, 208, 207, 206, 205, 205, 204, 203, 202, 202, 201, 200, 199, 199, 198,
+    197, 196, 196, 195, 194, 193, 193, 192, 191, 191, 190, 189, 188, 188, 187, 186,
+    185, 185, 184, 183, 182, 182, 181, 180, 179, 179, 178, 177, 176, 176, 175, 174};
+static uint64_t ora_msm_gas(uint64_t len, uint64_t rec, uint64_t mul_gas) {
+    uint64_t k = len / rec;
+    if (k == 0) return 0;
+    uint64_t d = ORA_DISCOUNT[k < 128 ? k - 1 : 127];
+    return k * mul_gas * d / 1000;
+}
+EXPORT uint64_t oracle_g1multiexp_gas(uint64_t len) { return ora_msm_gas(len, 160, 12000); }
+EXPORT uint64_t oracle_g2multiexp_gas(uint64_t len) { return ora_msm_gas(len, 288, 55000); }
+EXPORT uint64_t oracle_pairing_gas(uint64_t len) {
+    uint64_t k = len / 384;
+    return k ? 115000 + 23000 * k : 0;
+}
+
+/* ------------------------------------------------------------------ test helpers */
+/* slow-definition subgroup tests, to validate the endomorphism tests */
+EXPORT int oracle_g1_in_subgroup(const uint8_t in[128], int slow) {
+    g1_aff a;
+    int rc = ora_decode_g1(&a, in);
+    if (rc) return -rc;
+    return slow ? g1_in_subgroup_slow(&a) : g1_in_subgroup(&a);
+}
+EXPORT int oracle_g2_in_subgroup(const uint8_t in[256], int slow) {
+    g2_aff a;
+    int rc = ora_decode_g2(&a, in);
+    if (rc) return -rc;
+    return slow ? g2_in_subgroup_slow(&a) : g2_in_subgroup(&a);
+}
+
+static uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/*
+ * Synthetic MSM input: P_i = [a + i*b]G for the group generator G, scalars k_i =
+ * four big-endian SplitMix64 outputs (uniform 256-bit, not reduced).  Points are produced by
+ * repeated addition and converted with one batched inversion.  a_le / b_le are 32-byte LE.
+ * Writes n records of (point || scalar) in EIP encoding.
+ */
+#define DEFINE_GEN(G, F, FNP, REC, PTB, ENCODE, GX, GY, SETXY)                                     \
+EXPORT int oracle_gen_##G##_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32],              \
+                                      const uint8_t b_le[32], uint64_t seed) {                     \
+    G##_aff gen;                                                                                   \
+    SETXY;                                                                                         \
+    G##_jac g, cur, step;                                                                          \
+    G##_from_affine(&g, &gen);                                                                     \
+    G##_mult(&cur, &g, a_le, 256);                                                                 \
+    G##_mult(&step, &g, b_le, 256);                                                                \
+    G##_jac *pts = malloc(n * sizeof *pts);                                                        \
+    F *pref = malloc(n * sizeof *pref);                                                            \
+    if (!pts || !pref) { free(pts); free(pref); return ORA_MEMORY_ERROR; }                         \
+    F run;                                                                                         \
+    FNP##one(&run);                                                                                \
+    for (size_t i = 0; i < n; i++) {                                                               \
+        pts[i] = cur;                                                                              \
+        pref[i] = run;                                                                             \
+        if (!G##_is_inf(&cur)) FNP##mul(&run, &run, &cur.z);                                       \
+        G##_add(&cur, &cur, &step);                                                                \
+    }                                                                                              \
+    F inv;                                                                                         \
+    FNP##inv(&inv, &run);                                                                          \
+    uint64_t s = seed;                                                                             \
+    for (size_t i = n; i-- > 0;) {                                                                 \
+        G##_aff a;                                                                                 \
+        if (G##_is_inf(&pts[i])) {                                                                 \
+            memset(&a, 0, sizeof a);                                                               \
+        } else {                                                                                   \
+            F zi, zi2, zi3;                                                                        \
+            FNP##mul(&zi, &inv, &pref[i]);                                                         \
+            FNP##mul(&inv, &inv, &pts[i].z);                                                       \
+            FNP##sqr(&zi2, &zi);                                                                   \
+            FNP##mul(&zi3, &zi2, &zi);                                                             \
+            FNP##mul(&a.x, &pts[i].x, &zi2);                                                       \
+            FNP##mul(&a.y, &pts[i].y, &zi3);                                                       \
+        }                                                                                          \
+        ENCODE(out + i * REC, &a);                                                                 \
+    }                                                                                              \
+    for (size_t i = 0; i < n; i++) {                                                               \
+        uint8_t *k = out + i * REC + PTB;                                                          \
+        for (int w = 0; w < 4; w++) {                                                              \
+            uint64_t v = splitmix64(&s);                                                           \
+            for (int b = 0; b < 8; b++) k[8 * w + b] = (uint8_t)(v >> (56 - 8 * b));               \
+        }                                                                                          \
+    }                                                                                              \
+    free(pts);                                                                                     \
+    free(pref);                                                                                    \
+    return ORA_SUCCESS;                                                                            \
+}
+
+DEFINE_GEN(g1, fp, fp_, 160, 128, ora_encode_g1, ORA_G1_X, ORA_G1_Y,
+           (fp_set(&gen.x, ORA_G1_X), fp_set(&gen.y, ORA_G1_Y)))
+DEFINE_GEN(g2, fp2, fp2_, 288, 256, ora_encode_g2, ORA_G2_X, ORA_G2_Y,
+           (fp2_set(&gen.x, ORA_G2_X), fp2_set(&gen.y, ORA_G2_Y)))
+
+/*
+ * Synthetic pairing input: pairs ([a0 + i*a1]G1, [b0 + i*b1]G2), i < k.
+ * The caller (Python, big integers) fixes up the last pair so that the product is 1.
+ */
+EXPORT int oracle_gen_pairing_input(uint8_t *out, size_t k, const uint8_t a0[32], const uint8_t a1[32],
+                                    const uint8_t b0[32], const uint8_t b1[32]) {
+    uint8_t *t1 = malloc(k * 160), *t2 = malloc(k * 288);
+    if (!t1 || !t2) { free(t1); free(t2); return ORA_MEMORY_ERROR; }
+    oracle_gen_g1_msm_input(t1, k, a0, a1, 1);
+    oracle_gen_g2_msm_input(t2, k, b0, b1, 1);
+    for (size_t i = 0; i < k; i++) {
+        memcpy(out + i * 384, t1 + i * 160, 128);
+        memcpy(out + i * 384 + 128, t2 + i * 288, 256);
+    }
+    free(t1);
+    free(t2);
+    return ORA_SUCCESS;
+}
+
+/* raw Miller loop / final exponentiation on encoded points, for cross-checks in tests:
+ * out = 576 bytes = 12 Fp coefficients (c0.a0.c0, c0.a0.c1, c0.a1.c0, ...) 48-byte big-endian */
+EXPORT int oracle_pairing_fp12(uint8_t out[576], const uint8_t in[384], int do_final_exp) {
+    g1_aff p;
+    g2_aff q;
+    int rc = ora_decode_g1(&p, in);
+    if (rc) return rc;
+    rc = ora_decode_g2(&q, in + 128);
+    if (rc) return rc;
+    fp12 f;
+    ora_miller_loop(&f, &q, &p);
+    if (do_final_exp) ora_final_exp(&f, &f);
+    for (int k = 0; k < 6; k++) {
+        uint8_t tmp[128];
+        ora_fp2_to_bytes(tmp, fp12_coeff(&f, k));
+        memcpy(out + k * 96, tmp + 16, 48);
+        memcpy(out + k * 96 + 48, tmp + 80, 48);
+    }
+    return ORA_SUCCESS;
+}
