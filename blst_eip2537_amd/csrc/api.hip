@@ -1,0 +1,394 @@
+// C-ABI of libeip2537_hip.so: the reference's 13 precompile entry points (include/eip2537.h),
+// its gas API, and the device / sharding extensions (include/eip2537_hip.h).
+//
+// Length rules, validation order and error codes restate the reference's precompile logic:
+//   bls12_g1add / g1mul        reference src/eip2537.c:434-524
+//   bls12_g1multiexp*          reference src/eip2537.c:541-708  (here: one GPU Pippenger for all n)
+//   bls12_g2add / g2mul / g2multiexp*   reference src/eip2537.c:722-998
+//   bls12_pairing              reference src/eip2537.c:1020-1081
+//   bls12_map_*                reference src/eip2537.c:1094-1165
+//   gas                        reference src/eip2537.c:1168-1271
+// Single-pair operations (add, mul, map) are host code of this library (BASELINE config 1 is
+// "CPU plumbing, no GPU"); the multiexp and pairing paths have no CPU implementation here at all:
+// without a working HIP device they fail loudly with EIP2537_MEMORY_ERROR.
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "codec.h"
+#include "pairing.h"
+#include "engine.h"
+#include "../../include/eip2537.h"
+#include "../../include/eip2537_hip.h"
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace eip {
+
+hipError_t DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+static std::mutex g_mu;         // serialises GPU calls: the ABI has no handle to hang state on
+static Engine g_engine;
+static int g_device_request = -1;
+static int g_window_override = 0;
+
+static bool engine_init_locked() {
+    if (g_engine.ready) return true;
+    int ndev = 0;
+    hipError_t er = hipGetDeviceCount(&ndev);
+    if (er != hipSuccess || ndev == 0) {
+        fprintf(stderr, "[eip2537_hip] FATAL: no HIP device available (%s); the multiexp / pairing "
+                        "path has no CPU fallback\n", er == hipSuccess ? "0 devices" : hipGetErrorString(er));
+        return false;
+    }
+    int dev = g_device_request;
+    if (dev < 0) {
+        const char *env = getenv("EIP2537_HIP_DEVICE");
+        dev = env ? atoi(env) : 0;
+    }
+    if (dev >= ndev) dev = dev % ndev;
+    if (hipSetDevice(dev) != hipSuccess) { fprintf(stderr, "[eip2537_hip] FATAL: hipSetDevice(%d) failed\n", dev); return false; }
+    g_engine.device = dev;
+    bool ok = hipStreamCreateWithFlags(&g_engine.stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&g_engine.stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&g_engine.stream3, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&g_engine.ev_start) == hipSuccess && hipEventCreate(&g_engine.ev_stop) == hipSuccess &&
+              hipEventCreate(&g_engine.ev_a) == hipSuccess && hipEventCreate(&g_engine.ev_b) == hipSuccess &&
+              hipEventCreate(&g_engine.ev_j2) == hipSuccess && hipEventCreate(&g_engine.ev_j3) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[eip2537_hip] FATAL: stream/event creation failed\n"); return false; }
+    g_engine.ready = true;
+    return true;
+}
+
+// Host -> device staging of the caller's buffer.  The copy is complete before this returns, so
+// the caller's pointer is never retained (Go / Rust own the memory: SURVEY.md 8b "Ownership").
+static int stage_input(Engine *e, const void *in, size_t len) {
+    if (e->input.reserve(len) != hipSuccess) {
+        fprintf(stderr, "[eip2537_hip] hipMalloc of %zu staging bytes failed\n", len);
+        return E_MEMORY_ERROR;
+    }
+    if (hipSetDevice(e->device) != hipSuccess) return E_MEMORY_ERROR;
+    if (hipMemcpy(e->input.p, in, len, hipMemcpyHostToDevice) != hipSuccess) {
+        fprintf(stderr, "[eip2537_hip] host-to-device copy failed\n");
+        return E_MEMORY_ERROR;
+    }
+    return E_SUCCESS;
+}
+
+// ---- host-side single operations -------------------------------------------------------
+template <class F> static int host_decode_point(Aff<F> &out, const byte *in) {
+    uint32_t w[Wire<F>::kPointWords];
+    memcpy(w, in, sizeof w);
+    return decode_point<F>(out, w);
+}
+template <class F> static void host_encode_point(byte *out, const Aff<F> &a) {
+    uint32_t w[Wire<F>::kPointWords];
+    encode_point<F>(w, a);
+    memcpy(out, w, sizeof w);
+}
+template <class F> static int host_add(byte *out, const byte *in, size_t in_len) {
+    const size_t pb = Wire<F>::kPointWords * 4;
+    if (in_len != 2 * pb) return E_INVALID_LENGTH;
+    Aff<F> a, b;
+    int st = host_decode_point<F>(a, in);
+    if (st) return st;
+    st = host_decode_point<F>(b, in + pb);
+    if (st) return st;
+    host_encode_point<F>(out, to_affine(madd(from_affine(a), b)));
+    return E_SUCCESS;
+}
+template <class F> static int host_mul(byte *out, const byte *in, size_t in_len) {
+    const size_t pb = Wire<F>::kPointWords * 4;
+    if (in_len != pb + 32) return E_INVALID_LENGTH;
+    Aff<F> a;
+    int st = host_decode_point<F>(a, in);
+    if (st) return st;
+    uint32_t sw[8], k[8];
+    memcpy(sw, in + pb, 32);
+    decode_scalar(k, sw);
+    host_encode_point<F>(out, to_affine(scalar_mul(a, k, 256)));
+    return E_SUCCESS;
+}
+
+template <class F> static int msm_dispatch(Engine *e, const void *d_in, size_t n, uint32_t *pw);
+template <> int msm_dispatch<Fp>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g1_device(e, d_in, n, pw, g_window_override); }
+template <> int msm_dispatch<Fp2>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g2_device(e, d_in, n, pw, g_window_override); }
+
+// mode: 0 = host input (stage it), 1 = device input; want_partial: write the XYZZ partial
+template <class F>
+static int msm_entry(byte *out, const void *in, size_t n, bool device_input, bool want_partial) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!engine_init_locked()) return E_MEMORY_ERROR;
+    Engine *e = &g_engine;
+    if (hipSetDevice(e->device) != hipSuccess) return E_MEMORY_ERROR;
+    const void *d_in = in;
+    if (!device_input) {
+        int st = stage_input(e, in, n * Wire<F>::kMsmRecWords * 4);
+        if (st) return st;
+        d_in = e->input.p;
+    }
+    Xyzz<F> acc;
+    int st = msm_dispatch<F>(e, d_in, n, reinterpret_cast<uint32_t *>(&acc));
+    if (st) return st;
+    if (want_partial) {
+        memcpy(out, &acc, sizeof acc);
+    } else {
+        host_encode_point<F>(out, to_affine(acc));
+    }
+    return E_SUCCESS;
+}
+template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_len) {
+    const size_t rec = Wire<F>::kMsmRecWords * 4;
+    if (in_len == 0 || in_len % rec) return E_INVALID_LENGTH;      // before touching `in`
+    return msm_entry<F>(out, in, in_len / rec, false, false);
+}
+template <class F> static int msm_combine(byte *out, const uint8_t *partials, size_t count) {
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (size_t i = 0; i < count; i++) {
+        Xyzz<F> p;
+        memcpy(&p, partials + i * sizeof p, sizeof p);
+        acc = add(acc, p);
+    }
+    host_encode_point<F>(out, to_affine(acc));
+    return E_SUCCESS;
+}
+
+static void pairing_finish(byte *out, const Fp12 &ml) {
+    bool one = is_one(final_exp(ml));
+    memset(out, 0, 32);
+    if (one) out[31] = 1;
+}
+static int pairing_entry(byte *out, const void *in, size_t k, bool device_input, bool want_partial) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!engine_init_locked()) return E_MEMORY_ERROR;
+    Engine *e = &g_engine;
+    if (hipSetDevice(e->device) != hipSuccess) return E_MEMORY_ERROR;
+    const void *d_in = in;
+    if (!device_input) {
+        int st = stage_input(e, in, k * 384);
+        if (st) return st;
+        d_in = e->input.p;
+    }
+    Fp12 ml;
+    int st = pairing_device(e, d_in, k, reinterpret_cast<uint32_t *>(&ml));
+    if (st) return st;
+    if (want_partial) memcpy(out, &ml, sizeof ml); else pairing_finish(out, ml);
+    return E_SUCCESS;
+}
+
+static uint64_t msm_gas(uint64_t len, uint64_t rec, uint64_t mul_gas);
+
+// ------------------------------------------------------------------ synthetic inputs (bench / tests)
+// Records i in [start, start+n) of the SURVEY.md 8d workload: P_i = [a + i*b]G (G the group
+// generator), k_i = four big-endian SplitMix64 outputs at stream position 4*i (uniform 256-bit,
+// not reduced mod r -- the distribution of the reference bench, rust/benches/eip2537_benches.rs:61-63).
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t index) {
+    uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <class F> static Aff<F> group_generator();
+template <> Aff<Fp> group_generator<Fp>() { return Aff<Fp>{Fp{{K_G1_X}}, Fp{{K_G1_Y}}}; }
+template <> Aff<Fp2> group_generator<Fp2>() {
+    return Aff<Fp2>{Fp2{Fp{{K_G2_X_C0}}, Fp{{K_G2_X_C1}}}, Fp2{Fp{{K_G2_Y_C0}}, Fp{{K_G2_Y_C1}}}};
+}
+template <class F>
+static int gen_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32], const uint8_t b_le[32],
+                         uint64_t seed, uint64_t start, size_t rec_bytes, bool with_scalars) {
+    const size_t pb = Wire<F>::kPointWords * 4;
+    uint32_t a[8], b[8];
+    memcpy(a, a_le, 32);
+    memcpy(b, b_le, 32);
+    Aff<F> g = group_generator<F>();
+    Xyzz<F> step = scalar_mul(g, b, 256);
+    Xyzz<F> cur;
+    {   // cur = [a]G + [start]([b]G), start as a 64-bit scalar
+        Xyzz<F> acc = xyzz_inf<F>();
+        for (int i = 63; i >= 0; i--) {
+            acc = dbl(acc);
+            if ((start >> i) & 1ull) acc = add(acc, step);
+        }
+        cur = add(scalar_mul(g, a, 256), acc);
+    }
+    std::vector<Xyzz<F>> pts(n);
+    std::vector<F> pref(n);
+    F run = f_one<F>();
+    for (size_t i = 0; i < n; i++) {
+        pts[i] = cur;
+        pref[i] = run;
+        if (!is_inf(cur)) run = mul(run, mul(cur.zz, cur.zzz));
+        cur = add(cur, step);
+    }
+    F invr = inv(run);
+    for (size_t i = n; i-- > 0;) {
+        Aff<F> af{f_zero<F>(), f_zero<F>()};
+        if (!is_inf(pts[i])) {
+            F t = mul(invr, pref[i]);                    // 1 / (zz * zzz)
+            invr = mul(invr, mul(pts[i].zz, pts[i].zzz));
+            af.x = mul(pts[i].x, mul(t, pts[i].zzz));
+            af.y = mul(pts[i].y, mul(t, pts[i].zz));
+        }
+        host_encode_point<F>(out + i * rec_bytes, af);
+    }
+    if (with_scalars) {
+        for (size_t i = 0; i < n; i++) {
+            uint8_t *k = out + i * rec_bytes + pb;
+            for (int w = 0; w < 4; w++) {
+                uint64_t v = splitmix64_at(seed, 4 * (start + i) + w);
+                for (int bb = 0; bb < 8; bb++) k[8 * w + bb] = (uint8_t)(v >> (56 - 8 * bb));
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace eip
+
+using namespace eip;
+
+// ------------------------------------------------------------------ reference ABI
+API EIP2537_ERROR bls12_g1add(byte out[128], const byte in[256], size_t in_len) { return (EIP2537_ERROR)host_add<Fp>(out, in, in_len); }
+API EIP2537_ERROR bls12_g1mul(byte out[128], const byte in[160], size_t in_len) { return (EIP2537_ERROR)host_mul<Fp>(out, in, in_len); }
+API EIP2537_ERROR bls12_g2add(byte out[256], const byte in[512], size_t in_len) { return (EIP2537_ERROR)host_add<Fp2>(out, in, in_len); }
+API EIP2537_ERROR bls12_g2mul(byte out[256], const byte in[288], size_t in_len) { return (EIP2537_ERROR)host_mul<Fp2>(out, in, in_len); }
+
+API EIP2537_ERROR bls12_g1multiexp(byte out[128], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp>(out, in, in_len); }
+API EIP2537_ERROR bls12_g1multiexp_naive(byte out[128], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp>(out, in, in_len); }
+API EIP2537_ERROR bls12_g1multiexp_bc(byte out[128], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp>(out, in, in_len); }
+API EIP2537_ERROR bls12_g2multiexp(byte out[256], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp2>(out, in, in_len); }
+API EIP2537_ERROR bls12_g2multiexp_naive(byte out[256], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp2>(out, in, in_len); }
+API EIP2537_ERROR bls12_g2multiexp_bc(byte out[256], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp2>(out, in, in_len); }
+
+API EIP2537_ERROR bls12_pairing(byte out[32], byte *in, size_t in_len) {
+    if (in_len == 0 || in_len % 384) return EIP2537_INVALID_LENGTH;
+    return (EIP2537_ERROR)pairing_entry(out, in, in_len / 384, false, false);
+}
+
+// map-to-curve: field-element validation follows the reference (:1097-1108, :1139-1150); the
+// SSWU + isogeny + cofactor-clearing body is SURVEY.md 8f rank 1 ("next") and not built yet.
+API EIP2537_ERROR bls12_map_fp_to_g1(byte out[128], const byte in[64], size_t in_len) {
+    (void)out;
+    if (in_len != 64) return EIP2537_INVALID_LENGTH;
+    uint32_t w[16];
+    memcpy(w, in, 64);
+    Fp u;
+    if (fp_decode(u, w) < 0) return EIP2537_INVALID_ELEMENT;
+    fprintf(stderr, "[eip2537_hip] bls12_map_fp_to_g1: not implemented in this build\n");
+    return EIP2537_ENCODING_ERROR;
+}
+API EIP2537_ERROR bls12_map_fp2_to_g2(byte out[256], const byte in[128], size_t in_len) {
+    (void)out;
+    if (in_len != 128) return EIP2537_INVALID_LENGTH;
+    uint32_t w[32];
+    memcpy(w, in, 128);
+    Fp2 u;
+    if (fp_decode(u, w) < 0) return EIP2537_INVALID_ELEMENT;
+    fprintf(stderr, "[eip2537_hip] bls12_map_fp2_to_g2: not implemented in this build\n");
+    return EIP2537_ENCODING_ERROR;
+}
+
+// ------------------------------------------------------------------ gas (reference :1168-1271)
+extern "C" {
+__attribute__((visibility("default"))) extern const uint64_t BLS12_G1ADD_GAS = 600;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_G1MUL_GAS = 12000;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_G2ADD_GAS = 4500;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_G2MUL_GAS = 55000;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_PAIRING_BASE_GAS = 115000;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_PAIRING_PAIR_GAS = 23000;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_MAP_FP_TO_G1_GAS = 5500;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_MAP_FP2_TO_G2_GAS = 110000;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_MULTIEXP_MULTIPLIER_GAS = 1000;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_MULTIEXP_DISCOUNT_TABLE_LEN = 128;
+__attribute__((visibility("default"))) extern const uint64_t BLS12_MULTIEXP_DISCOUNT[128] = {
+    1200, 888, 764, 641, 594, 547, 500, 453, 438, 423, 408, 394, 379, 364, 349, 334,
+    330, 326, 322, 318, 314, 310, 306, 302, 298, 294, 289, 285, 281, 277, 273, 269,
+    268, 266, 265, 263, 262, 260, 259, 257, 256, 254, 253, 251, 250, 248, 247, 245,
+    244, 242, 241, 239, 238, 236, 235, 233, 232, 231, 229, 228, 226, 225, 223, 222,
+    221, 220, 219, 219, 218, 217, 216, 216, 215, 214, 213, 213, 212, 211, 211, 210,
+    209, 208, 208, 207, 206, 205, 205, 204, 203, 202, 202, 201, 200, 199, 199, 198,
+    197, 196, 196, 195, 194, 193, 193, 192, 191, 191, 190, 189, 188, 188, 187, 186,
+    185, 185, 184, 183, 182, 182, 181, 180, 179, 179, 178, 177, 176, 176, 175, 174};
+}
+static uint64_t eip::msm_gas(uint64_t len, uint64_t rec, uint64_t mul_gas) {
+    uint64_t k = len / rec;
+    if (k == 0) return 0;
+    uint64_t d = BLS12_MULTIEXP_DISCOUNT[k < BLS12_MULTIEXP_DISCOUNT_TABLE_LEN ? k - 1 : BLS12_MULTIEXP_DISCOUNT_TABLE_LEN - 1];
+    return k * mul_gas * d / BLS12_MULTIEXP_MULTIPLIER_GAS;
+}
+API uint64_t bls12_g1add_gas(void) { return BLS12_G1ADD_GAS; }
+API uint64_t bls12_g1mul_gas(void) { return BLS12_G1MUL_GAS; }
+API uint64_t bls12_g1multiexp_gas(uint64_t len) { return msm_gas(len, 160, BLS12_G1MUL_GAS); }
+API uint64_t bls12_g2add_gas(void) { return BLS12_G2ADD_GAS; }
+API uint64_t bls12_g2mul_gas(void) { return BLS12_G2MUL_GAS; }
+API uint64_t bls12_g2multiexp_gas(uint64_t len) { return msm_gas(len, 288, BLS12_G2MUL_GAS); }
+API uint64_t bls12_pairing_gas(uint64_t len) {
+    uint64_t k = len / 384;
+    return k ? k * BLS12_PAIRING_PAIR_GAS + BLS12_PAIRING_BASE_GAS : 0;
+}
+API uint64_t bls12_map_fp_to_g1_gas(void) { return BLS12_MAP_FP_TO_G1_GAS; }
+API uint64_t bls12_map_fp2_to_g2_gas(void) { return BLS12_MAP_FP2_TO_G2_GAS; }
+
+// ------------------------------------------------------------------ extensions
+API int eip2537_hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_engine.ready) return g_engine.device == device || device < 0 ? 0 : E_MEMORY_ERROR;
+    g_device_request = device;
+    return engine_init_locked() ? 0 : E_MEMORY_ERROR;
+}
+API int eip2537_hip_g1multiexp_dev(uint8_t out[128], const void *d_in, size_t n) { return n ? msm_entry<Fp>(out, d_in, n, true, false) : E_INVALID_LENGTH; }
+API int eip2537_hip_g2multiexp_dev(uint8_t out[256], const void *d_in, size_t n) { return n ? msm_entry<Fp2>(out, d_in, n, true, false) : E_INVALID_LENGTH; }
+API int eip2537_hip_pairing_dev(uint8_t out[32], const void *d_in, size_t k) { return k ? pairing_entry(out, d_in, k, true, false) : E_INVALID_LENGTH; }
+API int eip2537_hip_g1msm_partial_dev(uint8_t *partial, const void *d_in, size_t n) { return n ? msm_entry<Fp>(partial, d_in, n, true, true) : E_INVALID_LENGTH; }
+API int eip2537_hip_g2msm_partial_dev(uint8_t *partial, const void *d_in, size_t n) { return n ? msm_entry<Fp2>(partial, d_in, n, true, true) : E_INVALID_LENGTH; }
+API int eip2537_hip_pairing_partial_dev(uint8_t *partial, const void *d_in, size_t k) { return k ? pairing_entry(partial, d_in, k, true, true) : E_INVALID_LENGTH; }
+API int eip2537_hip_g1msm_combine(uint8_t out[128], const uint8_t *partials, size_t count) { return msm_combine<Fp>(out, partials, count); }
+API int eip2537_hip_g2msm_combine(uint8_t out[256], const uint8_t *partials, size_t count) { return msm_combine<Fp2>(out, partials, count); }
+API int eip2537_hip_pairing_combine(uint8_t out[32], const uint8_t *partials, size_t count) {
+    Fp12 acc = fp12_one();
+    for (size_t i = 0; i < count; i++) {
+        Fp12 p;
+        memcpy(&p, partials + i * sizeof p, sizeof p);
+        acc = mul(acc, p);
+    }
+    pairing_finish(out, acc);
+    return 0;
+}
+API void eip2537_hip_last_timing(float *pipeline_ms, float *dominant_kernel_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (pipeline_ms) *pipeline_ms = g_engine.last_kernel_ms;
+    if (dominant_kernel_ms) *dominant_kernel_ms = g_engine.last_accum_ms;
+}
+API int eip2537_hip_set_window(int c) {
+    if (c != 0 && (c < 4 || c > 16)) return E_INVALID_LENGTH;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_window_override = c;
+    return 0;
+}
+
+// Synthetic workloads of SURVEY.md 8d (host code; used by bench.py and the tests, never by a precompile)
+API int eip2537_hip_gen_g1_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t seed, uint64_t start) {
+    return gen_msm_input<Fp>(out, n, a_le, b_le, seed, start, 160, true);
+}
+API int eip2537_hip_gen_g2_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t seed, uint64_t start) {
+    return gen_msm_input<Fp2>(out, n, a_le, b_le, seed, start, 288, true);
+}
+// pairs ([a0 + i*a1]G1, [b0 + i*b1]G2), i in [start, start+k)
+API int eip2537_hip_gen_pairing_input(uint8_t *out, size_t k, const uint8_t a0[32], const uint8_t a1[32],
+                                      const uint8_t b0[32], const uint8_t b1[32], uint64_t start) {
+    gen_msm_input<Fp>(out, k, a0, a1, 0, start, 384, false);
+    return gen_msm_input<Fp2>(out + 128, k, b0, b1, 0, start, 384, false);
+}

@@ -1,0 +1,329 @@
+// G1 / G2 multi-scalar multiplication on gfx950: Pippenger bucket method.
+//
+// Replaces the reference's MSM algorithms (naive loop src/eip2537.c:564-616, Bos-Coster heap
+// :619-708, G2 clones :851-998).  The output of the ABI is a canonical affine encoding, so any
+// correct algorithm is bit-identical to the reference's (SURVEY.md 8a "parity principle").
+//
+// Pipeline (all kernels on one stream; one thread per unit named in brackets):
+//   k_msm_decode   [record]  wire decode + validation + Montgomery form; AoS affine points;
+//                            signed c-bit window digits -> bucket histogram
+//   k_msm_scan     [1 block] exclusive scan of the histogram -> entry offsets, task offsets
+//   k_msm_scatter  [record]  counting-sort scatter of (point index, sign) by bucket
+//   k_msm_tasks    [bucket]  split every bucket into tasks of <= L entries
+//   k_msm_accum    [task]    XYZZ mixed additions over the task's entries        (dominant)
+//   k_msm_reduce   [segment] running-sum sum_j j*B_j over S buckets + offset multiple, then a
+//                            wavefront-shuffle tree and an LDS step -> one point per block
+//   host                     adds the few per-block points of each window, Horner over windows
+#include <algorithm>
+#include <stdio.h>
+#include <vector>
+#include "codec.h"
+#include "engine.h"
+
+namespace eip {
+
+#define HIPCHK(x)                                                                               \
+    do {                                                                                        \
+        hipError_t _e = (x);                                                                    \
+        if (_e != hipSuccess) {                                                                 \
+            fprintf(stderr, "[eip2537_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), \
+                    __FILE__, __LINE__);                                                        \
+            return E_MEMORY_ERROR;                                                              \
+        }                                                                                       \
+    } while (0)
+
+struct Task { uint32_t start, len; };
+
+MsmPlan msm_make_plan(uint32_t n, int c_override) {
+    MsmPlan best{};
+    double best_cost = 1e300;
+    for (int c = 4; c <= 16; c++) {
+        if (c_override && c != c_override) continue;
+        MsmPlan pl{};
+        pl.n = n;
+        pl.c = c;
+        pl.W = (256 + c - 1) / c;
+        pl.topbits = 256 - (pl.W - 1) * c;
+        pl.B = 1u << (c - 1);
+        pl.BT = 1u << pl.topbits;
+        pl.NB = (uint32_t)(pl.W - 1) * pl.B + pl.BT;
+        // mixed add ~10 products per (record, window); reduce ~2 full adds (~14 products) per
+        // bucket plus a fixed per-thread tail
+        double cost = (double)n * pl.W * 10.0 + (double)pl.NB * 30.0;
+        if (cost < best_cost) { best_cost = cost; best = pl; }
+    }
+    MsmPlan &pl = best;
+    pl.L = 64;
+    pl.S = pl.c >= 12 ? 16 : (pl.c >= 8 ? 8 : 4);
+    pl.max_entries = (uint64_t)n * pl.W;
+    pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
+    return pl;
+}
+
+// Signed window digits of an unreduced 256-bit scalar.  Windows 0..W-2 are signed with digits in
+// [-(B-1)..B]; the top window is unsigned and absorbs the last carry (value <= 2^topbits), so no
+// extra carry window exists.  fn(global bucket id, negate).
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const uint32_t k[8], const MsmPlan &pl, Fn &&fn) {
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = k[i];
+    const uint32_t c = (uint32_t)pl.c;
+    const uint32_t mask = (1u << c) - 1u;
+    uint32_t carry = 0;
+    for (int w = 0; w < pl.W - 1; w++) {
+        uint32_t d = (s[0] & mask) + carry;
+#pragma unroll
+        for (int i = 0; i < 7; i++) s[i] = (s[i] >> c) | (s[i + 1] << (32u - c));
+        s[7] >>= c;
+        uint32_t ng = d > pl.B ? 1u : 0u;
+        if (ng) d = (mask + 1u) - d;
+        carry = ng;
+        if (d) fn((uint32_t)w * pl.B + d - 1u, ng);
+    }
+    uint32_t d = s[0] + carry;
+    if (d) fn((uint32_t)(pl.W - 1) * pl.B + d - 1u, 0u);
+}
+
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts,
+             uint8_t *__restrict__ valid, uint32_t *__restrict__ counts, unsigned long long *err) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pl.n) return;
+    const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords;
+    Aff<F> a;
+    int st = decode_point<F>(a, w);
+    if (st != E_SUCCESS) {
+        atomicMin(err, ((unsigned long long)i << 3) | (unsigned long long)st);
+        valid[i] = 0;
+        return;
+    }
+    if (is_inf(a)) { valid[i] = 0; return; }
+    pts[i] = a;
+    valid[i] = 1;
+    uint32_t k[8];
+    decode_scalar(k, w + Wire<F>::kPointWords);
+    for_each_digit(k, pl, [&](uint32_t g, uint32_t) { atomicAdd(&counts[g], 1u); });
+}
+
+__global__ void __launch_bounds__(1024)
+k_msm_scan(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift,
+           uint32_t *__restrict__ offsets, uint32_t *__restrict__ taskoff, uint32_t *totals) {
+    __shared__ uint32_t se[1024], st[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (NB + 1023u) / 1024u;
+    const uint32_t lo = min(t * chunk, NB), hi = min(lo + chunk, NB);
+    const uint32_t lm = (1u << lshift) - 1u;
+    uint32_t e = 0, k = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t cnt = counts[i];
+        e += cnt;
+        k += (cnt + lm) >> lshift;
+    }
+    se[t] = e;
+    st[t] = k;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        uint32_t ve = t >= off ? se[t - off] : 0u, vt = t >= off ? st[t - off] : 0u;
+        __syncthreads();
+        se[t] += ve;
+        st[t] += vt;
+        __syncthreads();
+    }
+    uint32_t be = se[t] - e, bt = st[t] - k;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t cnt = counts[i];
+        offsets[i] = be;
+        taskoff[i] = bt;
+        be += cnt;
+        bt += (cnt + lm) >> lshift;
+    }
+    if (t == 1023u) {
+        taskoff[NB] = st[1023];
+        totals[0] = se[1023];
+        totals[1] = st[1023];
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_scatter(const uint32_t *__restrict__ in, MsmPlan pl, const uint8_t *__restrict__ valid,
+              const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
+              uint32_t *__restrict__ entries) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pl.n || !valid[i]) return;
+    const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords + Wire<F>::kPointWords;
+    uint32_t k[8];
+    decode_scalar(k, w);
+    for_each_digit(k, pl, [&](uint32_t g, uint32_t ng) {
+        uint32_t pos = offsets[g] + atomicAdd(&cursor[g], 1u);
+        entries[pos] = (i << 1) | ng;
+    });
+}
+
+__global__ void __launch_bounds__(256)
+k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+            const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks) {
+    uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= NB) return;
+    uint32_t cnt = counts[g];
+    if (!cnt) return;
+    uint32_t t0 = taskoff[g], off = offsets[g];
+    const uint32_t L = 1u << lshift;
+    for (uint32_t done = 0, j = 0; done < cnt; done += L, j++)
+        tasks[t0 + j] = Task{off + done, min(L, cnt - done)};
+}
+
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_accum(const Aff<F> *__restrict__ pts, const uint32_t *__restrict__ entries,
+            const Task *__restrict__ tasks, const uint32_t *__restrict__ totals,
+            Xyzz<F> *__restrict__ partial) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= totals[1]) return;
+    Task tk = tasks[t];
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (uint32_t e = 0; e < tk.len; e++) {
+        uint32_t ent = entries[tk.start + e];
+        Aff<F> p = pts[ent >> 1];
+        if (ent & 1u) p.y = neg(p.y);
+        acc = madd(acc, p);
+    }
+    partial[t] = acc;
+}
+
+// ---- wavefront shuffles of field elements and points (64 lanes)
+__device__ __forceinline__ Fp shfl_down(const Fp &a, int off) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = __shfl_down(a.l[i], off, 64);
+    return r;
+}
+__device__ __forceinline__ Fp2 shfl_down(const Fp2 &a, int off) { return Fp2{shfl_down(a.c0, off), shfl_down(a.c1, off)}; }
+template <class F> __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F> &p, int off) {
+    return Xyzz<F>{shfl_down(p.x, off), shfl_down(p.y, off), shfl_down(p.zz, off), shfl_down(p.zzz, off)};
+}
+
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_reduce(const Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, MsmPlan pl,
+             Xyzz<F> *__restrict__ winout) {
+    const int w = blockIdx.y;
+    const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
+    const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lo = seg * pl.S;
+    Xyzz<F> C = xyzz_inf<F>();
+    if (lo < nbw) {
+        const uint32_t hi = min(lo + pl.S, nbw);
+        Xyzz<F> R = xyzz_inf<F>(), Q = xyzz_inf<F>();
+        for (uint32_t v = hi; v > lo; v--) {
+            const uint32_t g = (uint32_t)w * pl.B + v - 1u;
+            const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+            for (uint32_t t = t0; t < t1; t++) R = add(R, partial[t]);
+            Q = add(Q, R);
+        }
+        // sum_{v in (lo, hi]} v * B_v = Q + lo * R
+        C = add(Q, small_mul(R, lo));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off >= 1; off >>= 1) {
+        Xyzz<F> o = shfl_down(C, off);
+        if (lane < off) C = add(C, o);
+    }
+    __shared__ Xyzz<F> sm[4];
+    if (lane == 0) sm[wave] = C;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        C = add(add(sm[0], sm[1]), add(sm[2], sm[3]));
+        winout[(size_t)w * gridDim.x + blockIdx.x] = C;
+    }
+}
+
+template <class F>
+static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
+    if (n == 0 || n >= (1ull << 31)) return E_MEMORY_ERROR;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 3u) != 0) {
+        fprintf(stderr, "[eip2537_hip] device input must be 4-byte aligned\n");
+        return E_MEMORY_ERROR;
+    }
+    MsmPlan pl = msm_make_plan((uint32_t)n, c_override);
+    if (pl.max_entries >= (1ull << 32)) return E_MEMORY_ERROR;
+    const uint32_t lshift = 6;   // L = 64
+    const uint32_t seg_per_win = (std::max(pl.B, pl.BT) + pl.S - 1) / pl.S;
+    const uint32_t red_blocks = (seg_per_win + 255u) / 256u;
+    const size_t nwin_out = (size_t)pl.W * red_blocks;
+
+    HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
+    HIPCHK(e->valid.reserve(n));
+    HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
+    HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
+    HIPCHK(e->cursor.reserve((size_t)pl.NB * 4));
+    HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
+    HIPCHK(e->entries.reserve(pl.max_entries * 4));
+    HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
+    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
+    HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
+    HIPCHK(e->misc.reserve(64));
+
+    hipStream_t s = e->stream;
+    auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
+    auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
+    HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
+    HIPCHK(hipMemsetAsync(totals, 0, 16, s));
+    HIPCHK(hipMemsetAsync(e->counts.p, 0, (size_t)pl.NB * 4, s));
+    HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)pl.NB * 4, s));
+
+    const uint32_t rec_blocks = (uint32_t)((n + 255) / 256);
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
+    auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
+    auto *valid = reinterpret_cast<uint8_t *>(e->valid.p);
+    auto *counts = reinterpret_cast<uint32_t *>(e->counts.p);
+    auto *offsets = reinterpret_cast<uint32_t *>(e->offsets.p);
+    auto *cursor = reinterpret_cast<uint32_t *>(e->cursor.p);
+    auto *taskoff = reinterpret_cast<uint32_t *>(e->taskoff.p);
+    auto *entries = reinterpret_cast<uint32_t *>(e->entries.p);
+    auto *tasks = reinterpret_cast<Task *>(e->tasks.p);
+    auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
+    auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
+
+    HIPCHK(hipEventRecord(e->ev_start, s));
+    hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, valid, counts, err);
+    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, s, counts, pl.NB, lshift, offsets, taskoff, totals);
+    hipLaunchKernelGGL(k_msm_scatter<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, valid, offsets, cursor, entries);
+    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks);
+    HIPCHK(hipEventRecord(e->ev_a, s));
+    hipLaunchKernelGGL(k_msm_accum<F>, dim3((pl.max_tasks + 255u) / 256u), dim3(256), 0, s, pts, entries, tasks, totals, partial);
+    HIPCHK(hipEventRecord(e->ev_b, s));
+    hipLaunchKernelGGL(k_msm_reduce<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
+    HIPCHK(hipEventRecord(e->ev_stop, s));
+    HIPCHK(hipGetLastError());
+
+    unsigned long long herr = 0;
+    std::vector<Xyzz<F>> hw(nwin_out);
+    HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hw.data(), winout, nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
+    if (herr != ~0ull) return (int)(herr & 7ull);
+
+    // Horner over windows on the host (W * c doublings + a handful of additions)
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (int w = pl.W - 1; w >= 0; w--) {
+        for (int d = 0; d < pl.c; d++) acc = dbl(acc);
+        for (uint32_t b = 0; b < red_blocks; b++) acc = add(acc, hw[(size_t)w * red_blocks + b]);
+    }
+    memcpy(partial_words, &acc, sizeof acc);
+    return E_SUCCESS;
+}
+
+int msm_g1_device(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
+    return msm_device_t<Fp>(e, d_in, n, partial_words, c_override);
+}
+int msm_g2_device(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
+    return msm_device_t<Fp2>(e, d_in, n, partial_words, c_override);
+}
+
+}  // namespace eip

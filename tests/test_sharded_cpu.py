@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: two gloo ranks shard one MSM / one pairing batch by record range, exchange
+their partials with all_gather and combine them with the product's host-side combine functions
+(include/eip2537_hip.h).  The per-shard partials come from the CPU oracle here (no GPU in this
+container); on the GPU box the same exchange runs in bench.py over RCCL."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import oracle
+from oracle import clib
+import bls12_381 as m
+from blst_eip2537_amd import Eip2537Executor as X
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+RM = (1 << 384) % m.P
+mont = lambda v: (v * RM % m.P).to_bytes(48, "little")
+def g1_partial(enc):            # affine (x,y) -> XYZZ partial (x, y, 1, 1); infinity -> zz = 0
+    if enc == bytes(128): return bytes(192)
+    x, y = int.from_bytes(enc[16:64], "big"), int.from_bytes(enc[80:128], "big")
+    return mont(x) + mont(y) + mont(1) + mont(1)
+A, B, SEED, N = 0x1f3a5c7e9b2d, 0x123456789abcdef, 4242, 600
+per = N // world
+full = X.gen_msm_input("g1", N, A, B, SEED)
+mine = X.gen_msm_input("g1", per, A, B, SEED, start=rank * per)     # each rank builds only its shard
+assert mine == full[rank * per * 160:(rank + 1) * per * 160]
+rc, part_aff = clib.call("bls12_g1multiexp", mine)
+assert rc == 0
+t = torch.frombuffer(bytearray(g1_partial(part_aff)), dtype=torch.uint8)
+gathered = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(gathered, t)
+out = X.combine("eip2537_hip_g1msm_combine", [bytes(g.numpy().tobytes()) for g in gathered])
+rc, want = clib.call("bls12_g1multiexp", full)
+assert rc == 0 and out == want, "sharded MSM != whole MSM"
+# pairing: shard the pairs, exchange Fp12 Miller products, one final exponentiation
+K = 8
+a0, a1, b0, b1 = 5, 7, 11, 13
+pairs = bytearray(X.gen_pairing_input(K, a0, a1, b0, b1))
+s = sum((a0 + i * a1) * (b0 + i * b1) for i in range(K - 1)) % m.R
+pairs[(K - 1) * 384:] = m.encode_g1(m.g1_mul(m.G1, (-s) % m.R)) + m.encode_g2(m.G2)
+kp = K // world
+shard = bytes(pairs[rank * kp * 384:(rank + 1) * kp * 384])
+acc = m.F12_ONE
+for o in range(0, len(shard), 384):          # Miller product of the shard, via the oracle, as Montgomery words
+    raw = clib.pairing_fp12(shard[o:o + 384], final_exp=False)
+    coeffs = [int.from_bytes(raw[i * 48:(i + 1) * 48], "big") for i in range(12)]
+    f = tuple(tuple((coeffs[c6 * 6 + c2 * 2], coeffs[c6 * 6 + c2 * 2 + 1]) for c2 in range(3)) for c6 in range(2))
+    acc = m.f12_mul(acc, f)
+blob = b"".join(mont(c) for c6 in acc for c2 in c6 for c in c2)
+t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+gathered = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(gathered, t)
+out = X.combine("eip2537_hip_pairing_combine", [bytes(g.numpy().tobytes()) for g in gathered])
+assert out == bytes(31) + b"\x01", "sharded pairing check failed"
+pairs[0:128] = m.encode_g1(m.g1_mul(m.G1, 12345))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_shard_gather_combine(tmp_path, clib, X):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "ok" in o
