@@ -89,7 +89,8 @@ HD Fp sub(const Fp &a, const Fp &b) {
 HD Fp neg(const Fp &a) { return sub(fp_zero(), a); }
 HD Fp dbl(const Fp &a) { return add(a, a); }
 
-// Montgomery product, 12 x 32-bit CIOS.  Each inner step is one v_mad_u64_u32 plus carry adds.
+// Montgomery product, 12 x 32-bit CIOS (round-1 first version; kept as the comparison point of
+// tools/fpmul_bench.hip and as a host-side cross-check of fp_mul_cols28).
 HD Fp fp_mul_limbs32(const Fp &a, const Fp &b) {
     const Fp p = fp_p();
     uint32_t t[13];
@@ -120,6 +121,105 @@ HD Fp fp_mul_limbs32(const Fp &a, const Fp &b) {
     Fp r;
 #pragma unroll
     for (int i = 0; i < 12; i++) r.l[i] = t[i];
+    return fp_reduce_once(r);
+}
+
+// Device Montgomery product.  The operands arrive as canonical 12 x 32-bit limbs and are
+// re-sliced into 14 x 28-bit limbs so that every multiply-add of the schoolbook product and of
+// the reduction is ONE v_mad_u64_u32 accumulating in place into a 64-bit column: 28 terms of
+// < 2^56 never overflow, so no carry is handled inside the loops (the 32-bit-limb CIOS spent
+// more than half of its instructions on carry plumbing; measured 1.9x slower, profiles/).
+// Reduction removes 13 x 28 + 20 = 384 bits, so R stays 2^384 and the result is bit-identical
+// to the host's 6 x 64-bit product.
+HD Fp fp_mul_cols28(const Fp &a, const Fp &b) {
+    const uint32_t p28[14] = {K_P28};
+    const uint32_t M28 = 0x0fffffffu;
+    uint32_t al[14], bl[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const int bit = 28 * k, i = bit >> 5, s = bit & 31;
+        uint32_t va = a.l[i] >> s, vb = b.l[i] >> s;
+        if (s > 4 && i + 1 < 12) { va |= a.l[i + 1] << (32 - s); vb |= b.l[i + 1] << (32 - s); }
+        al[k] = va & M28;
+        bl[k] = vb & M28;
+    }
+    uint64_t col[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) col[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+#pragma unroll
+        for (int j = 0; j < 14; j++) col[i + j] += (uint64_t)al[j] * bl[i];
+        // last step clears only 20 bits: 13 * 28 + 20 = 384
+        const uint32_t m = ((uint32_t)col[i] * K_N0_28) & (i < 13 ? M28 : 0x000fffffu);
+#pragma unroll
+        for (int j = 0; j < 14; j++) col[i + j] += (uint64_t)m * p28[j];
+        if (i < 13) col[i + 1] += col[i] >> 28;
+    }
+    // digits 13..27 hold (result << 20); propagate carries, then cut 32-bit words at bit 20
+    uint32_t d[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        uint64_t v = col[13 + k] + carry;
+        d[k] = (uint32_t)v & M28;
+        carry = v >> 28;
+    }
+    d[15] = 0;
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 20 + 32 * w, q = bit / 28, o = bit % 28;
+        uint64_t t = (uint64_t)d[q] | ((uint64_t)d[q + 1] << 28) | ((uint64_t)(q + 2 < 16 ? d[q + 2] : 0u) << 56);
+        r.l[w] = (uint32_t)(t >> o);
+    }
+    return fp_reduce_once(r);
+}
+// Squaring: the 91 cross products are computed once against a doubled operand.
+HD Fp fp_sqr_cols28(const Fp &a) {
+    const uint32_t p28[14] = {K_P28};
+    const uint32_t M28 = 0x0fffffffu;
+    uint32_t al[14], a2[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const int bit = 28 * k, i = bit >> 5, s = bit & 31;
+        uint32_t va = a.l[i] >> s;
+        if (s > 4 && i + 1 < 12) va |= a.l[i + 1] << (32 - s);
+        al[k] = va & M28;
+        a2[k] = al[k] << 1;
+    }
+    uint64_t col[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) col[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        col[2 * i] += (uint64_t)al[i] * al[i];
+#pragma unroll
+        for (int j = i + 1; j < 14; j++) col[i + j] += (uint64_t)a2[j] * al[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t m = ((uint32_t)col[i] * K_N0_28) & (i < 13 ? M28 : 0x000fffffu);
+#pragma unroll
+        for (int j = 0; j < 14; j++) col[i + j] += (uint64_t)m * p28[j];
+        if (i < 13) col[i + 1] += col[i] >> 28;
+    }
+    uint32_t d[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        uint64_t v = col[13 + k] + carry;
+        d[k] = (uint32_t)v & M28;
+        carry = v >> 28;
+    }
+    d[15] = 0;
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 20 + 32 * w, q = bit / 28, o = bit % 28;
+        uint64_t t = (uint64_t)d[q] | ((uint64_t)d[q + 1] << 28) | ((uint64_t)(q + 2 < 16 ? d[q + 2] : 0u) << 56);
+        r.l[w] = (uint32_t)(t >> o);
+    }
     return fp_reduce_once(r);
 }
 
@@ -157,7 +257,13 @@ inline Fp fp_mul_limbs64(const Fp &a, const Fp &b) {
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(EIP_DEBUG_OLD_MUL)
 static __device__ __noinline__ Fp fp_mul_outlined(Fp a, Fp b) { return fp_mul_limbs32(a, b); }
+static __device__ __noinline__ Fp fp_sqr_outlined(Fp a) { return fp_mul_limbs32(a, a); }
+#else
+static __device__ __noinline__ Fp fp_mul_outlined(Fp a, Fp b) { return fp_mul_cols28(a, b); }
+static __device__ __noinline__ Fp fp_sqr_outlined(Fp a) { return fp_sqr_cols28(a); }
+#endif
 #endif
 
 HD Fp mul(const Fp &a, const Fp &b) {
@@ -167,7 +273,13 @@ HD Fp mul(const Fp &a, const Fp &b) {
     return fp_mul_limbs64(a, b);
 #endif
 }
-HD Fp sqr(const Fp &a) { return mul(a, a); }
+HD Fp sqr(const Fp &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_sqr_outlined(a);
+#else
+    return fp_mul_limbs64(a, a);
+#endif
+}
 
 // a^e for a plain little-endian exponent of nwords 32-bit words (MSB-first square and multiply)
 HD Fp fp_pow(const Fp &a, const uint32_t *e, int nwords) {
@@ -197,16 +309,30 @@ HD Fp2 sub(const Fp2 &a, const Fp2 &b) { return Fp2{sub(a.c0, b.c0), sub(a.c1, b
 HD Fp2 neg(const Fp2 &a) { return Fp2{neg(a.c0), neg(a.c1)}; }
 HD Fp2 dbl(const Fp2 &a) { return Fp2{dbl(a.c0), dbl(a.c1)}; }
 HD Fp2 conj(const Fp2 &a) { return Fp2{a.c0, neg(a.c1)}; }
-HD Fp2 mul(const Fp2 &a, const Fp2 &b) {
+HD Fp2 fp2_mul_body(const Fp2 &a, const Fp2 &b) {
     Fp t0 = mul(a.c0, b.c0);
     Fp t1 = mul(a.c1, b.c1);
     Fp t2 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
     return Fp2{sub(t0, t1), sub(sub(t2, t0), t1)};
 }
-HD Fp2 sqr(const Fp2 &a) {
+HD Fp2 fp2_sqr_body(const Fp2 &a) {
     Fp m = mul(a.c0, a.c1);
     return Fp2{mul(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
 }
+// On the device the Fp2 product and square are out of line as well.  Besides keeping the code
+// objects small this is a correctness guard: with fp_mul_cols28 and everything above it inlined,
+// hipcc 7.2 -O3 miscompiled k_pair_check_g2 (256 VGPR + 256 AGPR + scratch spills; the same
+// source was correct at -O1, with the 32-bit CIOS product, and in a smaller kernel) -- found by
+// the GPU parity tests, isolated with tools/debug_pair2.hip.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __noinline__ Fp2 fp2_mul_outlined(Fp2 a, Fp2 b) { return fp2_mul_body(a, b); }
+static __device__ __noinline__ Fp2 fp2_sqr_outlined(Fp2 a) { return fp2_sqr_body(a); }
+HD Fp2 mul(const Fp2 &a, const Fp2 &b) { return fp2_mul_outlined(a, b); }
+HD Fp2 sqr(const Fp2 &a) { return fp2_sqr_outlined(a); }
+#else
+HD Fp2 mul(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
+HD Fp2 sqr(const Fp2 &a) { return fp2_sqr_body(a); }
+#endif
 HD Fp2 mul_fp(const Fp2 &a, const Fp &s) { return Fp2{mul(a.c0, s), mul(a.c1, s)}; }
 HD Fp2 mul_xi(const Fp2 &a) { return Fp2{sub(a.c0, a.c1), add(a.c0, a.c1)}; }   // * (1 + u)
 HD Fp2 inv(const Fp2 &a) {

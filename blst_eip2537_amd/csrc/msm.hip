@@ -107,20 +107,13 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
     for_each_digit(k, pl, [&](uint32_t g, uint32_t) { atomicAdd(&counts[g], 1u); });
 }
 
-__global__ void __launch_bounds__(1024)
-k_msm_scan(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift,
-           uint32_t *__restrict__ offsets, uint32_t *__restrict__ taskoff, uint32_t *totals) {
-    __shared__ uint32_t se[1024], st[1024];
+// Three-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
+//   k_msm_scan_sums  [1024 buckets per block]  block totals of (entries, tasks)
+//   k_msm_scan_top   [1 block]                 exclusive scan of the block totals
+//   k_msm_scan_apply [1024 buckets per block]  local scan + block base -> offsets, taskoff
+__device__ __forceinline__ void block_scan_1024(uint32_t &e, uint32_t &k, uint32_t *se, uint32_t *st) {
+    // inclusive Hillis-Steele scan of (e, k) over the 1024 threads of the block
     const uint32_t t = threadIdx.x;
-    const uint32_t chunk = (NB + 1023u) / 1024u;
-    const uint32_t lo = min(t * chunk, NB), hi = min(lo + chunk, NB);
-    const uint32_t lm = (1u << lshift) - 1u;
-    uint32_t e = 0, k = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t cnt = counts[i];
-        e += cnt;
-        k += (cnt + lm) >> lshift;
-    }
     se[t] = e;
     st[t] = k;
     __syncthreads();
@@ -131,18 +124,42 @@ k_msm_scan(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift,
         st[t] += vt;
         __syncthreads();
     }
-    uint32_t be = se[t] - e, bt = st[t] - k;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t cnt = counts[i];
-        offsets[i] = be;
-        taskoff[i] = bt;
-        be += cnt;
-        bt += (cnt + lm) >> lshift;
-    }
-    if (t == 1023u) {
-        taskoff[NB] = st[1023];
-        totals[0] = se[1023];
-        totals[1] = st[1023];
+    e = se[t];
+    k = st[t];
+}
+__global__ void __launch_bounds__(1024)
+k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, uint32_t *__restrict__ blk) {
+    __shared__ uint32_t se[1024], st[1024];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t lm = (1u << lshift) - 1u;
+    uint32_t cnt = i < NB ? counts[i] : 0u;
+    uint32_t e = cnt, k = (cnt + lm) >> lshift;
+    block_scan_1024(e, k, se, st);
+    if (threadIdx.x == 1023u) { blk[2 * blockIdx.x] = e; blk[2 * blockIdx.x + 1] = k; }
+}
+__global__ void __launch_bounds__(1024)
+k_msm_scan_top(uint32_t *__restrict__ blk, uint32_t nblk, uint32_t NB, uint32_t *__restrict__ taskoff, uint32_t *totals) {
+    __shared__ uint32_t se[1024], st[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t e0 = t < nblk ? blk[2 * t] : 0u, k0 = t < nblk ? blk[2 * t + 1] : 0u;
+    uint32_t e = e0, k = k0;
+    block_scan_1024(e, k, se, st);
+    if (t < nblk) { blk[2 * t] = e - e0; blk[2 * t + 1] = k - k0; }     // exclusive bases
+    if (t == 1023u) { taskoff[NB] = k; totals[0] = e; totals[1] = k; }
+}
+__global__ void __launch_bounds__(1024)
+k_msm_scan_apply(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, const uint32_t *__restrict__ blk,
+                 uint32_t *__restrict__ offsets, uint32_t *__restrict__ taskoff) {
+    __shared__ uint32_t se[1024], st[1024];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t lm = (1u << lshift) - 1u;
+    uint32_t cnt = i < NB ? counts[i] : 0u;
+    uint32_t e0 = cnt, k0 = (cnt + lm) >> lshift;
+    uint32_t e = e0, k = k0;
+    block_scan_1024(e, k, se, st);
+    if (i < NB) {
+        offsets[i] = blk[2 * blockIdx.x] + e - e0;
+        taskoff[i] = blk[2 * blockIdx.x + 1] + k - k0;
     }
 }
 
@@ -265,6 +282,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
     HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
+    HIPCHK(e->scalars.reserve(2 * 1024 * 4));     // scan block totals
+    if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
     hipStream_t s = e->stream;
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
@@ -289,7 +308,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
 
     HIPCHK(hipEventRecord(e->ev_start, s));
     hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, valid, counts, err);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, s, counts, pl.NB, lshift, offsets, taskoff, totals);
+    const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
+    auto *blk = reinterpret_cast<uint32_t *>(e->scalars.p);
+    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
+    hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, valid, offsets, cursor, entries);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks);
     HIPCHK(hipEventRecord(e->ev_a, s));
