@@ -10,6 +10,7 @@
 //   k_msm_scan     [1 block] exclusive scan of the histogram -> entry offsets, task offsets
 //   k_msm_scatter  [record]  counting-sort scatter of (point index, sign) by bucket
 //   k_msm_tasks    [bucket]  split every bucket into tasks of <= L entries
+//   k_msm_task_*   [task]    counting sort of the tasks by length (equal trip counts per wave)
 //   k_msm_accum    [task]    XYZZ mixed additions over the task's entries        (dominant)
 //   k_msm_reduce   [segment] running-sum sum_j j*B_j over S buckets + offset multiple, then a
 //                            wavefront-shuffle tree and an LDS step -> one point per block
@@ -192,18 +193,69 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
         tasks[t0 + j] = Task{off + done, min(L, cnt - done)};
 }
 
+
+// Tasks sorted by length, longest first: bucket loads are Poisson distributed, so without this
+// a wave of k_msm_accum runs for the longest of its 64 tasks (~70 % lane utilisation at 2^20).
+// Counting sort on len in [1, 64]: per-block LDS histogram -> 64 global counters -> a one-wave
+// scan -> per-block range reservation -> permutation.
+__global__ void __launch_bounds__(256)
+k_msm_task_hist(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenhist) {
+    __shared__ uint32_t h[65];
+    if (threadIdx.x < 65) h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < totals[1]) atomicAdd(&h[tasks[t].len], 1u);
+    __syncthreads();
+    if (threadIdx.x < 65 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(64)
+k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ lenoff) {
+    // lane i owns length 64 - i (longest first); exclusive prefix over lanes
+    const uint32_t i = threadIdx.x;
+    uint32_t v = lenhist[64 - i], incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)i >= off) incl += o;
+    }
+    lenoff[64 - i] = incl - v;
+    if (i == 0) lenoff[0] = 0;
+}
+__global__ void __launch_bounds__(256)
+k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenoff,
+                uint32_t *__restrict__ perm) {
+    __shared__ uint32_t h[65], base[65];
+    if (threadIdx.x < 65) h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t len = 0, local = 0;
+    if (t < totals[1]) { len = tasks[t].len; local = atomicAdd(&h[len], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 65 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&lenoff[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (len) perm[base[len] + local] = t;
+}
+
+// field type the accumulate loop computes in: Fp -> FpI (inlined products), Fp2 unchanged
+template <class F> struct AccumField { using T = F; };
+template <> struct AccumField<Fp> { using T = FpI; };
+
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_accum(const Aff<F> *__restrict__ pts, const uint32_t *__restrict__ entries,
-            const Task *__restrict__ tasks, const uint32_t *__restrict__ totals,
-            Xyzz<F> *__restrict__ partial) {
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= totals[1]) return;
+k_msm_accum(const Aff<F> *__restrict__ pts_, const uint32_t *__restrict__ entries,
+            const Task *__restrict__ tasks, const uint32_t *__restrict__ perm,
+            const uint32_t *__restrict__ totals, Xyzz<F> *__restrict__ partial_) {
+    using T = typename AccumField<F>::T;
+    static_assert(sizeof(Aff<T>) == sizeof(Aff<F>) && sizeof(Xyzz<T>) == sizeof(Xyzz<F>), "layout");
+    const Aff<T> *__restrict__ pts = reinterpret_cast<const Aff<T> *>(pts_);
+    Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= totals[1]) return;
+    const uint32_t t = perm[slot];
     Task tk = tasks[t];
-    Xyzz<F> acc = xyzz_inf<F>();
+    Xyzz<T> acc = xyzz_inf<T>();
     for (uint32_t e = 0; e < tk.len; e++) {
         uint32_t ent = entries[tk.start + e];
-        Aff<F> p = pts[ent >> 1];
+        Aff<T> p = pts[ent >> 1];
         if (ent & 1u) p.y = neg(p.y);
         acc = madd(acc, p);
     }
@@ -282,7 +334,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
     HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scalars.reserve(2 * 1024 * 4));     // scan block totals
+    HIPCHK(e->scalars.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
+    HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
     hipStream_t s = e->stream;
@@ -310,13 +363,20 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, valid, counts, err);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
     auto *blk = reinterpret_cast<uint32_t *>(e->scalars.p);
+    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
+    auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
+    HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, valid, offsets, cursor, entries);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks);
+    const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
+    hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist);
+    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    hipLaunchKernelGGL(k_msm_accum<F>, dim3((pl.max_tasks + 255u) / 256u), dim3(256), 0, s, pts, entries, tasks, totals, partial);
+    hipLaunchKernelGGL(k_msm_accum<F>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
     hipLaunchKernelGGL(k_msm_reduce<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
