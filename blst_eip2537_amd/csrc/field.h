@@ -323,7 +323,7 @@ HD Fp2 fp2_sqr_body(const Fp2 &a) {
 // objects small this is a correctness guard: with fp_mul_cols28 and everything above it inlined,
 // hipcc 7.2 -O3 miscompiled k_pair_check_g2 (256 VGPR + 256 AGPR + scratch spills; the same
 // source was correct at -O1, with the 32-bit CIOS product, and in a smaller kernel) -- found by
-// the GPU parity tests, isolated with tools/debug_pair2.hip.
+// the GPU parity tests, isolated by compiling that kernel alone at -O1 / -O3 and with either product.
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __noinline__ Fp2 fp2_mul_outlined(Fp2 a, Fp2 b) { return fp2_mul_body(a, b); }
 static __device__ __noinline__ Fp2 fp2_sqr_outlined(Fp2 a) { return fp2_sqr_body(a); }

@@ -1,16 +1,27 @@
-// Batched pairing check on gfx950: one (G1, G2) pair per lane.
+// Batched pairing check on gfx950.
 //
 // Replaces the reference's sequential loop (src/eip2537.c:1033-1068): per pair decode G1, G1
 // subgroup test, decode G2, G2 subgroup test, Miller loop, running Fp12 product; then ONE final
 // exponentiation for the whole batch (:1070) and the == 1 test (:1076).
 //
-// Three independent kernels run concurrently on three streams:
-//   k_pair_check_g1  [pair]  decode + on-curve + G1 membership  (phi(P) == -[z^2]P)
-//   k_pair_check_g2  [pair]  decode + on-curve + G2 membership  (psi(Q) == [z]Q)
-//   k_pair_miller    [pair]  Miller loop f_i, then a per-wave Fp12 product tree over shuffles
+// The product of Miller functions is reorganised so that no lane ever carries an Fp12 through
+// the 63-step loop.  With l_{i,s} the line of pair i at step s (68 steps: 63 doublings, 5
+// additions) the batch value is
+//        F = prod_i f_i,   f_i = (...((l_{i,0})^2 l_{i,1})^2 ...)        =>
+//        F = (...((L_0)^2 L_1)^2 ...),   L_s = prod_i l_{i,s}
+// because squaring distributes over the product.  So:
+//   k_pair_lines   [pair]   one pair per lane: walk T = Q, 2Q, ... on the twist (Fp2 only) and
+//                           store the 68 sparse lines (a0, a1 xP, a4 yP); the walk ends at
+//                           T = [|z|]Q, which IS the G2 membership test psi(Q) == -[|z|]Q
+//   k_pair_check_g1 [pair]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
+//   k_pair_tree    [16 lines of one step per 8-lane group]  each Fp12 is spread over a lane
+//                           group (one Fp2 coefficient per lane); sparse line products, then a
+//                           per-wave product tree over shuffles and an LDS step across waves
+//   k_pair_tree2   [step]   the few per-block products of a step -> L_s (same lane-group form)
+//   host                    63 squarings + 68 products over the L_s, conjugate, final
+//                           exponentiation, == 1     (once per call, like the reference)
 // Errors are merged with atomicMin on (pair << 4 | stage << 3 | code): lowest pair first, and
 // inside a pair the reference's order G1 decode -> G1 subgroup -> G2 decode -> G2 subgroup.
-// The host multiplies the per-wave products and runs the single final exponentiation.
 #include <stdio.h>
 #include <vector>
 #include "codec.h"
@@ -29,7 +40,10 @@ namespace eip {
         }                                                                                       \
     } while (0)
 
-static constexpr int kPairWords = 96;   // 384 bytes
+static constexpr int kPairWords = 96;    // 384 bytes
+static constexpr int kSteps = 68;        // 63 doublings + 5 additions for |z| = 0xd201000000010000
+
+struct LineRec { Fp2 a0, a1, a4; };      // l = a0 + a1 v + a4 v w   (a1, a4 already scaled by xP, yP)
 
 __global__ void __launch_bounds__(64)
 k_pair_check_g1(const uint32_t *__restrict__ in, uint32_t k, unsigned long long *err) {
@@ -42,88 +56,193 @@ k_pair_check_g1(const uint32_t *__restrict__ in, uint32_t k, unsigned long long 
 }
 
 __global__ void __launch_bounds__(64)
-k_pair_check_g2(const uint32_t *__restrict__ in, uint32_t k, unsigned long long *err) {
+k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
     uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= k) return;
-    Aff<Fp2> q;
-    int st = decode_point<Fp2>(q, in + (size_t)i * kPairWords + 32);
-    if (st == E_SUCCESS && !in_g2(q)) st = E_NOT_IN_SUBGROUP;
-    if (st != E_SUCCESS) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)st);
+    Aff<Fp> P;
+    Aff<Fp2> Q;
+    int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
+    int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
+    if (s2 != E_SUCCESS) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
+    const bool q_live = s2 == E_SUCCESS && !is_inf(Q);
+    const bool contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
+    LineRec one{fp2_one(), fp2_zero(), fp2_zero()};
+    if (!q_live) {
+        for (int s = 0; s < kSteps; s++) lines[(size_t)s * k + i] = one;
+        return;
+    }
+    MillerT T{Q.x, Q.y, fp2_one()};
+    const uint64_t z = K_Z_ABS;
+    int s = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        Line l = miller_dbl_step(T);
+        lines[(size_t)s * k + i] = contributes ? LineRec{l.a0, mul_fp(l.a1, P.x), mul_fp(l.a4, P.y)} : one;
+        s++;
+        if ((z >> bit) & 1ull) {
+            l = miller_add_step(T, Q);
+            lines[(size_t)s * k + i] = contributes ? LineRec{l.a0, mul_fp(l.a1, P.x), mul_fp(l.a4, P.y)} : one;
+            s++;
+        }
+    }
+    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T
+    //   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
+    Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
+    Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
+    Fp2 zz = sqr(T.z);
+    bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
+    if (!in_sub) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
-__device__ __forceinline__ Fp shfl_down(const Fp &a, int off) {
+// ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
+// In the product trees an Fp12 element g = sum_k g_k w^k (g_k in Fp2, w^6 = xi) lives in one
+// 8-lane group: lane `sub` (0..5) holds g_sub, lanes 6 and 7 idle.  A lane then needs ~24
+// VGPRs per element instead of 144 (one-lane Fp12 products spilled ~6 KB of scratch and ran
+// ~10x slower per field product), and a dense product costs each lane 6 Fp2 products instead of
+// 18.  Operands move between lanes with ds_bpermute (wavefront shuffles).
+// Tower <-> w-power order:  [c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2] = [g0 g2 g4 g1 g3 g5].
+__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = __shfl_down(a.l[i], off, 64);
+    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
     return r;
 }
-__device__ __forceinline__ Fp2 shfl_down(const Fp2 &a, int off) { return Fp2{shfl_down(a.c0, off), shfl_down(a.c1, off)}; }
-__device__ __forceinline__ Fp6 shfl_down(const Fp6 &a, int off) { return Fp6{shfl_down(a.a0, off), shfl_down(a.a1, off), shfl_down(a.a2, off)}; }
-__device__ __forceinline__ Fp12 shfl_down(const Fp12 &a, int off) { return Fp12{shfl_down(a.c0, off), shfl_down(a.c1, off)}; }
+__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
+__device__ __forceinline__ int tower_slot(int sub) { return (sub & 1) * 3 + (sub >> 1); }
 
+// out_k = sum_i a_i b_{k-i}, indices mod 6, times xi when the index wrapped
+__device__ __forceinline__ Fp2 grp_mul(const Fp2 &a, const Fp2 &b, int sub, int gbase) {
+    Fp2 acc = fp2_zero();
+    for (int i = 0; i < 6; i++) {
+        int j = sub - i;
+        const bool wrap = j < 0;
+        if (wrap) j += 6;
+        Fp2 ai = shfl_from(a, gbase + i);
+        Fp2 bj = shfl_from(b, gbase + (j & 7));
+        Fp2 t = mul(ai, bj);
+        Fp2 tx = mul_xi(t);
+        acc = add(acc, wrap ? tx : t);
+    }
+    return acc;
+}
+// f * (a0 + a1 w^2 + a4 w^3)
+__device__ __forceinline__ Fp2 grp_mul_line(const Fp2 &f, const LineRec &l, int sub, int gbase) {
+    int j2 = sub - 2, j3 = sub - 3;
+    const bool w2 = j2 < 0, w3 = j3 < 0;
+    if (w2) j2 += 6;
+    if (w3) j3 += 6;
+    Fp2 f2 = shfl_from(f, gbase + (j2 & 7)), f3 = shfl_from(f, gbase + (j3 & 7));
+    Fp2 t0 = mul(f, l.a0);
+    Fp2 t2 = mul(f2, l.a1);
+    Fp2 t3 = mul(f3, l.a4);
+    Fp2 t2x = mul_xi(t2), t3x = mul_xi(t3);
+    return add(add(t0, w2 ? t2x : t2), w3 ? t3x : t3);
+}
+// product of the 8 groups of a wave, left in group 0
+__device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, int gbase) {
+    const int gi = lane >> 3;
+    for (int step = 1; step < 8; step <<= 1) {
+        Fp2 partner = shfl_from(acc, (lane + 8 * step) & 63);
+        if ((gi & (2 * step - 1)) == 0) acc = grp_mul(acc, partner, sub, gbase);
+    }
+}
+
+static constexpr int kGroupLines = 16;      // lines folded serially by one group before the tree
+
+// grid (blocks, 68 steps), 256 threads = 32 groups: each group folds kGroupLines lines of its
+// step into a dense element, then wave tree (shuffles) and an LDS step across the 4 waves.
+__global__ void __launch_bounds__(256)
+k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk_out) {
+    __shared__ Fp2 sm[4][6];
+    const int s = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, gbase = lane & ~7;
+    const uint32_t g = blockIdx.x * 32u + (threadIdx.x >> 3);
+    Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
+    for (int j = 0; j < kGroupLines; j++) {
+        const uint32_t i = g * kGroupLines + j;
+        if (i < k) {
+            LineRec l = lines[(size_t)s * k + i];
+            acc = grp_mul_line(acc, l, sub, gbase);
+        }
+    }
+    wave_group_product(acc, lane, sub, gbase);
+    if (lane < 6) sm[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < 8) {
+        for (int w = 1; w < 4; w++) {
+            Fp2 partner = sm[w][sub < 6 ? sub : 0];
+            acc = grp_mul(acc, partner, sub, 0);
+        }
+        if (sub < 6) blk_out[((size_t)s * gridDim.x + blockIdx.x) * 6 + tower_slot(sub)] = acc;
+    }
+}
+
+// one wave per step: fold the per-block products (tower-layout Fp12 = 6 Fp2) into L_s
 __global__ void __launch_bounds__(64)
-k_pair_miller(const uint32_t *__restrict__ in, uint32_t k, Fp12 *__restrict__ wave_out) {
-    uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    Fp12 f = fp12_one();
-    if (i < k) {
-        Aff<Fp> p;
-        Aff<Fp2> q;
-        int s1 = decode_point<Fp>(p, in + (size_t)i * kPairWords);
-        int s2 = decode_point<Fp2>(q, in + (size_t)i * kPairWords + 32);
-        if (s1 == E_SUCCESS && s2 == E_SUCCESS) f = miller_loop(p, q);   // else: result discarded by the caller
+k_pair_tree2(const Fp2 *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ step_out) {
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x, sub = lane & 7, gbase = lane & ~7, gi = lane >> 3;
+    Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
+    for (uint32_t b = gi; b < nblk; b += 8) {
+        Fp2 partner = blk_out[((size_t)s * nblk + b) * 6 + tower_slot(sub < 6 ? sub : 0)];
+        acc = grp_mul(acc, partner, sub, gbase);
     }
-    const int lane = threadIdx.x & 63;
-    for (int off = 32; off >= 1; off >>= 1) {
-        Fp12 o = shfl_down(f, off);
-        if (lane < off) f = mul(f, o);
-    }
-    if (lane == 0) wave_out[blockIdx.x] = f;
+    wave_group_product(acc, lane, sub, gbase);
+    if (lane < 6) step_out[(size_t)s * 6 + tower_slot(lane)] = acc;
 }
 
 int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
-    if (k == 0 || k >= (1ull << 31)) return E_MEMORY_ERROR;
+    if (k == 0 || k >= (1ull << 27)) return E_MEMORY_ERROR;
     if ((reinterpret_cast<uintptr_t>(d_in) & 3u) != 0) {
         fprintf(stderr, "[eip2537_hip] device input must be 4-byte aligned\n");
         return E_MEMORY_ERROR;
     }
     const uint32_t blocks = (uint32_t)((k + 63) / 64);
+    const uint32_t tree_blocks = (uint32_t)((k + 32 * kGroupLines - 1) / (32 * kGroupLines));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->winout.reserve((size_t)blocks * sizeof(Fp12)));
+    HIPCHK(e->partial.reserve((size_t)kSteps * k * sizeof(LineRec)));
+    HIPCHK(e->winout.reserve(((size_t)kSteps * tree_blocks + kSteps) * sizeof(Fp12)));
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
-    auto *wave_out = reinterpret_cast<Fp12 *>(e->winout.p);
+    auto *lines = reinterpret_cast<LineRec *>(e->partial.p);
+    auto *blk_out = reinterpret_cast<Fp2 *>(e->winout.p);                 // [step][block] tower-layout Fp12
+    auto *step_out = blk_out + (size_t)kSteps * tree_blocks * 6;           // [step] Fp12
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
 
     hipStream_t s = e->stream;
     HIPCHK(hipMemsetAsync(err, 0xFF, 8, s));
     HIPCHK(hipEventRecord(e->ev_start, s));
-    // fork: the two membership kernels run beside the Miller loops
+    // fork: the G1 membership kernel runs beside the line walk
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_start, 0));
-    HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_start, 0));
     hipLaunchKernelGGL(k_pair_check_g1, dim3(blocks), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
-    hipLaunchKernelGGL(k_pair_check_g2, dim3(blocks), dim3(64), 0, e->stream3, in, (uint32_t)k, err);
-    HIPCHK(hipEventRecord(e->ev_a, s));
-    hipLaunchKernelGGL(k_pair_miller, dim3(blocks), dim3(64), 0, s, in, (uint32_t)k, wave_out);
-    HIPCHK(hipEventRecord(e->ev_b, s));
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
-    HIPCHK(hipEventRecord(e->ev_j3, e->stream3));
+    HIPCHK(hipEventRecord(e->ev_a, s));
+    hipLaunchKernelGGL(k_pair_lines, dim3(blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
+    HIPCHK(hipEventRecord(e->ev_b, s));
+    hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, (uint32_t)k, blk_out);
+    hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
-    HIPCHK(hipStreamWaitEvent(s, e->ev_j3, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
     unsigned long long herr = 0;
-    std::vector<Fp12> parts(blocks);
+    std::vector<Fp12> L(kSteps);
     HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(parts.data(), wave_out, (size_t)blocks * sizeof(Fp12), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
     if (herr != ~0ull) return (int)(herr & 7ull);
 
-    Fp12 acc = parts[0];
-    for (uint32_t b = 1; b < blocks; b++) acc = mul(acc, parts[b]);
-    memcpy(ml_words, &acc, sizeof acc);
+    // F = (...((L_0)^2 L_1)^2 ...): square before every doubling step, conjugate because z < 0
+    Fp12 F = fp12_one();
+    const uint64_t z = K_Z_ABS;
+    int si = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        F = mul(sqr(F), L[si++]);
+        if ((z >> bit) & 1ull) F = mul(F, L[si++]);
+    }
+    F = conj(F);
+    memcpy(ml_words, &F, sizeof F);
     return E_SUCCESS;
 }
 
