@@ -10,9 +10,10 @@
 //        F = prod_i f_i,   f_i = (...((l_{i,0})^2 l_{i,1})^2 ...)        =>
 //        F = (...((L_0)^2 L_1)^2 ...),   L_s = prod_i l_{i,s}
 // because squaring distributes over the product.  So:
-//   k_pair_lines   [pair]   one pair per lane: walk T = Q, 2Q, ... on the twist (Fp2 only) and
-//                           store the 68 sparse lines (a0, a1 xP, a4 yP); the walk ends at
-//                           T = [|z|]Q, which IS the G2 membership test psi(Q) == -[|z|]Q
+//   k_pair_lines   [pair, 4 lanes each]  walk T = Q, 2Q, ... on the twist (Fp2 only), the
+//                           independent products of a step dealt over the 4 lanes; store the
+//                           68 sparse lines (a0, a1 xP, a4 yP); the walk ends at T = [|z|]Q,
+//                           which IS the G2 membership test psi(Q) == -[|z|]Q
 //   k_pair_check_g1 [pair]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
 //   k_pair_tree    [16 lines of one step per 8-lane group]  each Fp12 is spread over a lane
 //                           group (one Fp2 coefficient per lane); sparse line products, then a
@@ -55,32 +56,87 @@ k_pair_check_g1(const uint32_t *__restrict__ in, uint32_t k, unsigned long long 
     if (st != E_SUCCESS) atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)st);
 }
 
+// ---- line walk, 4 lanes per pair --------------------------------------------------------------
+// A lone wave issues one VALU instruction every ~4-8 cycles, so one pair per lane made the
+// 63-step walk a 2400-product serial chain on 64 waves.  Here a pair owns a 4-lane group: every
+// lane keeps the whole running point T, and the independent Fp2 products of a doubling step are
+// dealt one per lane in three rounds ([X^2 Y^2 Z^2 YZ], [B^2 (X+B)^2 E^2 EX], [E ZZ, Z3 ZZ,
+// E(D-X3)]), the results exchanged with shuffles; the cheap linear steps are replicated.
+__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
+    return r;
+}
+__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
+__device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
+    Fp2 o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        o.c0.l[i] = r == 0 ? a.c0.l[i] : r == 1 ? b.c0.l[i] : r == 2 ? c.c0.l[i] : d.c0.l[i];
+        o.c1.l[i] = r == 0 ? a.c1.l[i] : r == 1 ? b.c1.l[i] : r == 2 ? c.c1.l[i] : d.c1.l[i];
+    }
+    return o;
+}
+// same result as miller_dbl_step (pairing.h), products dealt over the 4 lanes of the group
+__device__ __forceinline__ Line miller_dbl_step4(MillerT &T, int r, int gbase) {
+    Fp2 pr = mul(sel4(r, T.x, T.y, T.z, T.y), sel4(r, T.x, T.y, T.z, T.z));
+    const Fp2 A = shfl_from(pr, gbase), B = shfl_from(pr, gbase + 1), ZZ = shfl_from(pr, gbase + 2), YZ = shfl_from(pr, gbase + 3);
+    const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
+    pr = mul(sel4(r, B, XB, E, E), sel4(r, B, XB, E, T.x));
+    const Fp2 C = shfl_from(pr, gbase), t = shfl_from(pr, gbase + 1), F = shfl_from(pr, gbase + 2), EX = shfl_from(pr, gbase + 3);
+    const Fp2 D = dbl(sub(sub(t, A), C));
+    const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
+    pr = mul(sel4(r, E, Z3, E, E), sel4(r, ZZ, ZZ, sub(D, X3), ZZ));
+    const Fp2 EZ = shfl_from(pr, gbase), Z3ZZ = shfl_from(pr, gbase + 1), Ym = shfl_from(pr, gbase + 2);
+    Line l;
+    l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
+    l.a1 = neg(EZ);                   // -3X^2 Z^2
+    l.a4 = Z3ZZ;                      // 2YZ^3
+    T.x = X3;
+    T.y = sub(Ym, dbl(dbl(dbl(C))));
+    T.z = Z3;
+    return l;
+}
+// scale (a1, a4) by (xP, yP): four Fp products, one per lane; then lanes 0..2 store a0, a1, a4
+__device__ __forceinline__ void store_line4(LineRec *dst, const Line &l, const Aff<Fp> &P, bool contributes, int r, int gbase) {
+    Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
+    Fp q = mul(w, r < 2 ? P.x : P.y);
+    Fp2 a1{shfl_from(q, gbase), shfl_from(q, gbase + 1)}, a4{shfl_from(q, gbase + 2), shfl_from(q, gbase + 3)};
+    Fp2 v = r == 0 ? l.a0 : (r == 1 ? a1 : a4);
+    if (!contributes) v = r == 0 ? fp2_one() : fp2_zero();
+    if (r < 3) (&dst->a0)[r] = v;
+}
+
 __global__ void __launch_bounds__(64)
 k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
-    uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= k) return;
+    const int lane = threadIdx.x & 63, r = lane & 3, gbase = lane & ~3;
+    const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
+    if (i >= k) return;                       // uniform within a 4-lane group
     Aff<Fp> P;
     Aff<Fp2> Q;
     int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
     int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
-    if (s2 != E_SUCCESS) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
+    if (s2 != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
     const bool q_live = s2 == E_SUCCESS && !is_inf(Q);
     const bool contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-    LineRec one{fp2_one(), fp2_zero(), fp2_zero()};
     if (!q_live) {
-        for (int s = 0; s < kSteps; s++) lines[(size_t)s * k + i] = one;
+        if (r < 3) {
+            Fp2 v = r == 0 ? fp2_one() : fp2_zero();
+            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[r] = v;
+        }
         return;
     }
     MillerT T{Q.x, Q.y, fp2_one()};
     const uint64_t z = K_Z_ABS;
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
-        Line l = miller_dbl_step(T);
-        lines[(size_t)s * k + i] = contributes ? LineRec{l.a0, mul_fp(l.a1, P.x), mul_fp(l.a4, P.y)} : one;
+        Line l = miller_dbl_step4(T, r, gbase);
+        store_line4(&lines[(size_t)s * k + i], l, P, contributes, r, gbase);
         s++;
-        if ((z >> bit) & 1ull) {
+        if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the 4 lanes
             l = miller_add_step(T, Q);
-            lines[(size_t)s * k + i] = contributes ? LineRec{l.a0, mul_fp(l.a1, P.x), mul_fp(l.a4, P.y)} : one;
+            store_line4(&lines[(size_t)s * k + i], l, P, contributes, r, gbase);
             s++;
         }
     }
@@ -90,7 +146,7 @@ k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ 
     Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
     Fp2 zz = sqr(T.z);
     bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
-    if (!in_sub) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+    if (!in_sub && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
 // ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
@@ -100,13 +156,6 @@ k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ 
 // ~10x slower per field product), and a dense product costs each lane 6 Fp2 products instead of
 // 18.  Operands move between lanes with ds_bpermute (wavefront shuffles).
 // Tower <-> w-power order:  [c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2] = [g0 g2 g4 g1 g3 g5].
-__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
-    return r;
-}
-__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
 __device__ __forceinline__ int tower_slot(int sub) { return (sub & 1) * 3 + (sub >> 1); }
 
 // out_k = sum_i a_i b_{k-i}, indices mod 6, times xi when the index wrapped
@@ -197,6 +246,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
         return E_MEMORY_ERROR;
     }
     const uint32_t blocks = (uint32_t)((k + 63) / 64);
+    const uint32_t line_blocks = (uint32_t)((k + 15) / 16);       // 4 lanes per pair
     const uint32_t tree_blocks = (uint32_t)((k + 32 * kGroupLines - 1) / (32 * kGroupLines));
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->partial.reserve((size_t)kSteps * k * sizeof(LineRec)));
@@ -215,7 +265,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipLaunchKernelGGL(k_pair_check_g1, dim3(blocks), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
-    hipLaunchKernelGGL(k_pair_lines, dim3(blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
+    hipLaunchKernelGGL(k_pair_lines, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
     hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, (uint32_t)k, blk_out);
     hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
