@@ -38,8 +38,65 @@ HD bool eq(const Fp &a, const Fp &b) {
     return acc == 0;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host paths: the same 48 bytes handled as 6 x 64-bit limbs.
+namespace hostfp {
+typedef unsigned __int128 u128;
+struct L6 { uint64_t w[6]; };
+inline L6 load(const Fp &a) { L6 r; memcpy(r.w, a.l, 48); return r; }
+inline Fp store(const L6 &a) { Fp r; memcpy(r.l, a.w, 48); return r; }
+inline L6 modulus() { static const uint32_t pw[12] = {K_P}; L6 r; memcpy(r.w, pw, 48); return r; }
+inline L6 reduce_once(const L6 &t) {
+    const L6 p = modulus();
+    L6 d;
+    uint64_t borrow = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 s = (u128)t.w[i] - p.w[i] - borrow;
+        d.w[i] = (uint64_t)s;
+        borrow = (uint64_t)(s >> 64) & 1;
+    }
+    const uint64_t keep_t = 0 - borrow;
+    L6 r;
+    for (int i = 0; i < 6; i++) r.w[i] = (t.w[i] & keep_t) | (d.w[i] & ~keep_t);
+    return r;
+}
+inline L6 add(const L6 &a, const L6 &b) {
+    L6 t;
+    uint64_t c = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 s = (u128)a.w[i] + b.w[i] + c;
+        t.w[i] = (uint64_t)s;
+        c = (uint64_t)(s >> 64);
+    }
+    return reduce_once(t);
+}
+inline L6 sub(const L6 &a, const L6 &b) {
+    const L6 p = modulus();
+    L6 d;
+    uint64_t borrow = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 s = (u128)a.w[i] - b.w[i] - borrow;
+        d.w[i] = (uint64_t)s;
+        borrow = (uint64_t)(s >> 64) & 1;
+    }
+    const uint64_t mask = 0 - borrow;
+    uint64_t c = 0;
+    L6 r;
+    for (int i = 0; i < 6; i++) {
+        u128 s = (u128)d.w[i] + (p.w[i] & mask) + c;
+        r.w[i] = (uint64_t)s;
+        c = (uint64_t)(s >> 64);
+    }
+    return r;
+}
+}  // namespace hostfp
+#endif
+
 // r = t - p if t >= p else t, for t < 2p (t fits in 384 bits)
 HD Fp fp_reduce_once(const Fp &t) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return hostfp::store(hostfp::reduce_once(hostfp::load(t)));
+#else
     const Fp p = fp_p();
     Fp d;
     uint32_t borrow = 0;
@@ -54,8 +111,12 @@ HD Fp fp_reduce_once(const Fp &t) {
 #pragma unroll
     for (int i = 0; i < 12; i++) r.l[i] = (t.l[i] & keep_t) | (d.l[i] & ~keep_t);
     return r;
+#endif
 }
 HD Fp add(const Fp &a, const Fp &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return hostfp::store(hostfp::add(hostfp::load(a), hostfp::load(b)));
+#else
     Fp t;
     uint32_t c = 0;
 #pragma unroll
@@ -65,8 +126,12 @@ HD Fp add(const Fp &a, const Fp &b) {
         c = (uint32_t)(s >> 32);
     }
     return fp_reduce_once(t);     // a + b < 2p < 2^384: no carry out
+#endif
 }
 HD Fp sub(const Fp &a, const Fp &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return hostfp::store(hostfp::sub(hostfp::load(a), hostfp::load(b)));
+#else
     const Fp p = fp_p();
     Fp d;
     uint32_t borrow = 0;
@@ -85,6 +150,7 @@ HD Fp sub(const Fp &a, const Fp &b) {
         c = (uint32_t)(s >> 32);
     }
     return r;
+#endif
 }
 HD Fp neg(const Fp &a) { return sub(fp_zero(), a); }
 HD Fp dbl(const Fp &a) { return add(a, a); }
@@ -227,11 +293,10 @@ HD Fp fp_sqr_cols28(const Fp &a) {
 // Host: the same 48 bytes as 6 x 64-bit limbs.
 inline Fp fp_mul_limbs64(const Fp &a, const Fp &b) {
     typedef unsigned __int128 u128;
-    static const uint32_t pw[12] = {K_P};
-    uint64_t A[6], B[6], Pm[6], t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    memcpy(A, a.l, 48);
-    memcpy(B, b.l, 48);
-    memcpy(Pm, pw, 48);
+    const hostfp::L6 la = hostfp::load(a), lb = hostfp::load(b), lp = hostfp::modulus();
+    const uint64_t *A = la.w, *B = lb.w, *Pm = lp.w;
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         uint64_t c = 0;
         for (int j = 0; j < 6; j++) {
@@ -250,9 +315,9 @@ inline Fp fp_mul_limbs64(const Fp &a, const Fp &b) {
         }
         t[5] = t[6] + c;
     }
-    Fp r;
-    memcpy(r.l, t, 48);
-    return fp_reduce_once(r);
+    hostfp::L6 r;
+    for (int i = 0; i < 6; i++) r.w[i] = t[i];
+    return hostfp::store(hostfp::reduce_once(r));
 }
 #endif
 

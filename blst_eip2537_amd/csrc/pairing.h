@@ -148,12 +148,35 @@ HD Fp12 miller_loop(const Aff<Fp> &P, const Aff<Fp2> &Q) {
 }
 
 // ------------------------------------------------------------------ final exponentiation
+// Squaring in the cyclotomic subgroup (Granger-Scott): three Fp4 squarings = 9 Fp2 squarings.
+// Valid only after the easy part of the final exponentiation; proven equal to the generic
+// square on such elements in oracle/pymodel/fastmodel.py (f12_cyclotomic_sqr).
+HD void fp4_sqr(Fp2 &c0, Fp2 &c1, const Fp2 &a, const Fp2 &b) {
+    Fp2 t0 = sqr(a), t1 = sqr(b);
+    c0 = add(mul_xi(t1), t0);
+    c1 = sub(sub(sqr(add(a, b)), t0), t1);
+}
+HD Fp12 cyclotomic_sqr(const Fp12 &f) {
+    Fp2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
+    Fp2 t0, t1, t2, t3;
+    fp4_sqr(t0, t1, z0, z1);
+    z0 = add(dbl(sub(t0, z0)), t0);
+    z1 = add(dbl(add(t1, z1)), t1);
+    fp4_sqr(t0, t1, z2, z3);
+    fp4_sqr(t2, t3, z4, z5);
+    z4 = add(dbl(sub(t0, z4)), t0);
+    z5 = add(dbl(add(t1, z5)), t1);
+    t0 = mul_xi(t3);
+    z2 = add(dbl(add(t0, z2)), t0);
+    z3 = add(dbl(sub(t2, z3)), t2);
+    return Fp12{Fp6{z0, z4, z3}, Fp6{z2, z1, z5}};
+}
 // g^z for g in the cyclotomic subgroup (inverse = conjugate)
 HD Fp12 exp_by_z(const Fp12 &g) {
     const uint64_t z = K_Z_ABS;
     Fp12 acc = g;
     for (int i = 62; i >= 0; i--) {
-        acc = sqr(acc);
+        acc = cyclotomic_sqr(acc);
         if ((z >> i) & 1ull) acc = mul(acc, g);
     }
     return conj(acc);

@@ -197,3 +197,30 @@ def g1_in_subgroup_fast(a):
         return True
     t = g1_mul(g1_mul(a, Z_ABS), Z_ABS)
     return g1_phi(a) == ec_neg(FP, t)
+
+
+# ---------------------------------------------------------------------------
+# Cyclotomic squaring (Granger-Scott) for elements of the cyclotomic subgroup
+# (after the easy part of the final exponentiation): 9 Fp2 squarings.
+# ---------------------------------------------------------------------------
+def _fp4_square(a, b):
+    t0 = f2_sqr(a)
+    t1 = f2_sqr(b)
+    c0 = f2_add(f2_mul(t1, XI), t0)
+    c1 = f2_sub(f2_sub(f2_sqr(f2_add(a, b)), t0), t1)
+    return c0, c1
+
+
+def f12_cyclotomic_sqr(f):
+    (z0, z4, z3), (z2, z1, z5) = f
+    t0, t1 = _fp4_square(z0, z1)
+    z0 = f2_add(f2_muls(f2_sub(t0, z0), 2), t0)
+    z1 = f2_add(f2_muls(f2_add(t1, z1), 2), t1)
+    t0, t1 = _fp4_square(z2, z3)
+    t2, t3 = _fp4_square(z4, z5)
+    z4 = f2_add(f2_muls(f2_sub(t0, z4), 2), t0)
+    z5 = f2_add(f2_muls(f2_add(t1, z5), 2), t1)
+    t0 = f2_mul(t3, XI)
+    z2 = f2_add(f2_muls(f2_add(t0, z2), 2), t0)
+    z3 = f2_add(f2_muls(f2_sub(t2, z3), 2), t2)
+    return ((z0, z4, z3), (z2, z1, z5))
