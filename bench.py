@@ -92,13 +92,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the multiexp / pairing path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a GPU to rehearse the
+    # sharded path on a 1-GPU box (everything but RCCL itself)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    X.init(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    X.init(dev_index)
 
     wl = args.workload
     log2n = args.log2n if args.log2n is not None else {"g1msm": 20, "g2msm": 16, "pairing": 12}[wl]
@@ -129,9 +137,14 @@ def main():
             out = X.dev_call(FULL[wl], d_in.data_ptr(), n_local)
         else:
             part = X.dev_call(PART[wl], d_in.data_ptr(), n_local)
-            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).cuda()
-            dist.all_gather_into_tensor(gather_buf, mine)
-            allp = bytes(gather_buf.cpu().numpy().tobytes())
+            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gather_buf, mine.cuda())
+                allp = bytes(gather_buf.cpu().numpy().tobytes())
+            else:
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                allp = b"".join(bytes(t.numpy().tobytes()) for t in parts)
             out = X.combine(COMB[wl], [allp[i * psz:(i + 1) * psz] for i in range(world)])
         p, k = X.last_timing()
         pipe_ms.append(p)
@@ -155,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,6 +180,22 @@ def main():
     if wl == "pairing":
         gold = bytes(31) + b"\x01"
     parity = None if gold is None else (out == gold)
+
+    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
+    # same command (counters cannot be read from inside the process); the summary is committed
+    # under profiles/ and only quoted when it was taken on the workload being run.
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("workload") == wl and tj.get("log2n") == log2n and world == 1:
+            traffic = tj["traffic_bytes_raw"]
+            traffic_note = ("PMC (FETCH_SIZE+WRITE_SIZE)*1024 per launch, raw; %.3g with the gfx950 x2 FETCH correction "
+                            "(calibrated for coalesced streams only; this kernel gathers 96-B points, 16 window passes "
+                            "over a 101 MB point array that stays in the 256 MB Infinity Cache). VALU issue: %.3f "
+                            "wave-instructions per SIMD-cycle. Source: profiles/r01_pmc_g1msm_2p20.csv"
+                            % (tj["traffic_bytes_fetch_x2"], tj["valu_wave_instr_per_simd_cycle"]))
 
     result = None
     if rank == 0:
@@ -186,7 +215,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "record-range shards x%d, RCCL all_gather of %d-byte partials" % (world, psz)},
             "bit_exact_vs_golden": parity,
             "roofline": {"bound": "hbm", "kernel": KERNEL[wl], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": k_ms, "device_pipeline_ms": p_ms,
                          "algorithmic_bytes_per_unit": REC[wl], "units_per_launch": n_local,
                          "note": "integer-VALU-bound by construction (SURVEY.md 8d): the HBM fraction is reported because the metric asks for it"},
