@@ -6,7 +6,7 @@
 //   bls12_g1multiexp*          reference src/eip2537.c:541-708  (here: one GPU Pippenger for all n)
 //   bls12_g2add / g2mul / g2multiexp*   reference src/eip2537.c:722-998
 //   bls12_pairing              reference src/eip2537.c:1020-1081
-//   bls12_map_*                reference src/eip2537.c:1094-1165
+//   bls12_map_*                reference src/eip2537.c:1094-1165  (host: csrc/h2c.h)
 //   gas                        reference src/eip2537.c:1168-1271
 // Single-pair operations (add, mul, map) are host code of this library (BASELINE config 1 is
 // "CPU plumbing, no GPU"); the multiexp and pairing paths have no CPU implementation here at all:
@@ -17,6 +17,7 @@
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
+#include "h2c.h"
 #include "engine.h"
 #include "../../include/eip2537.h"
 #include "../../include/eip2537_hip.h"
@@ -278,27 +279,27 @@ API EIP2537_ERROR bls12_pairing(byte out[32], byte *in, size_t in_len) {
     return (EIP2537_ERROR)pairing_entry(out, in, in_len / 384, false, false);
 }
 
-// map-to-curve: field-element validation follows the reference (:1097-1108, :1139-1150); the
-// SSWU + isogeny + cofactor-clearing body is SURVEY.md 8f rank 1 ("next") and not built yet.
+// map-to-curve: RFC 9380 map_to_curve of ONE field element, then cofactor clearing -- what the
+// reference gets from blst_map_to_g1/_g2(out, u, NULL) (:1113, :1155).  Host code (csrc/h2c.h).
 API EIP2537_ERROR bls12_map_fp_to_g1(byte out[128], const byte in[64], size_t in_len) {
-    (void)out;
     if (in_len != 64) return EIP2537_INVALID_LENGTH;
     uint32_t w[16];
     memcpy(w, in, 64);
     Fp u;
     if (fp_decode(u, w) < 0) return EIP2537_INVALID_ELEMENT;
-    fprintf(stderr, "[eip2537_hip] bls12_map_fp_to_g1: not implemented in this build\n");
-    return EIP2537_ENCODING_ERROR;
+    Aff<Fp> q = map_to_curve<Fp>(u);
+    host_encode_point<Fp>(out, to_affine(scalar_mul(q, K_ISO_H_EFF_G1, 64)));          // h_eff = 1 - z
+    return EIP2537_SUCCESS;
 }
 API EIP2537_ERROR bls12_map_fp2_to_g2(byte out[256], const byte in[128], size_t in_len) {
-    (void)out;
     if (in_len != 128) return EIP2537_INVALID_LENGTH;
     uint32_t w[32];
     memcpy(w, in, 128);
     Fp2 u;
     if (fp_decode(u, w) < 0) return EIP2537_INVALID_ELEMENT;
-    fprintf(stderr, "[eip2537_hip] bls12_map_fp2_to_g2: not implemented in this build\n");
-    return EIP2537_ENCODING_ERROR;
+    Aff<Fp2> q = map_to_curve<Fp2>(u);
+    host_encode_point<Fp2>(out, to_affine(scalar_mul(q, K_ISO_H_EFF_G2, K_ISO_H_EFF_G2_BITS)));   // h2 (3 z^2 - 3)
+    return EIP2537_SUCCESS;
 }
 
 // ------------------------------------------------------------------ gas (reference :1168-1271)

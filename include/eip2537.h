@@ -14,7 +14,7 @@
  *   bls12_g2add / g2mul          src/eip2537.h:48-49   host path of the engine
  *   bls12_g2multiexp(_naive,_bc) src/eip2537.h:50-52   GPU Pippenger (all three names)
  *   bls12_pairing                src/eip2537.h:54      GPU batched Miller loops
- *   bls12_map_fp_to_g1/_fp2_to_g2 src/eip2537.h:56-59  host path of the engine
+ *   bls12_map_fp_to_g1/_fp2_to_g2 src/eip2537.h:56-59  host path of the engine (RFC 9380 SSWU)
  *   gas constants / functions    src/eip2537.h:62-82   identical values
  *
  * Conventions (reference src/eip2537.c): `out` is caller-allocated and written only on success;

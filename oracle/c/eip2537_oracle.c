@@ -19,10 +19,13 @@
  *   Bos-Coster heap + driver                     src/eip2537.c:57-205, 619-708
  *   G2 clones                                    src/eip2537.c:208-259, 722-998
  *   bls12_pairing                                src/eip2537.c:1020-1081
+ *   bls12_map_fp_to_g1 / bls12_map_fp2_to_g2     src/eip2537.c:1094-1165 (RFC 9380 SSWU + isogeny,
+ *                                                pinned by the RFC's appendix-J vectors)
  *   gas schedule                                 src/eip2537.c:1168-1271
  */
 #include <stdlib.h>
 #include "ora_ec.h"
+#include "ora_iso_constants.h"
 
 enum {
     ORA_SUCCESS = 0, ORA_POINT_NOT_ON_CURVE, ORA_POINT_NOT_IN_SUBGROUP, ORA_INVALID_ELEMENT,
@@ -300,6 +303,117 @@ EXPORT int oracle_bls12_pairing(uint8_t *out, const uint8_t *in, size_t in_len) 
     ora_final_exp(&acc, &acc);
     memset(out, 0, 32);
     if (fp12_is_one(&acc)) out[31] = 1;
+    return ORA_SUCCESS;
+}
+
+
+/* ------------------------------------------------------------------ map to curve (:1094-1165) */
+static int fp_sgn0(const fp *a) { fp r; fp_from_mont(&r, a); return (int)(r.l[0] & 1); }
+static int fp2_sgn0(const fp2 *a) {
+    fp r0, r1;
+    fp_from_mont(&r0, &a->c0);
+    fp_from_mont(&r1, &a->c1);
+    int s0 = (int)(r0.l[0] & 1), z0 = fp_is_zero(&r0), s1 = (int)(r1.l[0] & 1);
+    return s0 | (z0 & s1);
+}
+/* square root in Fp2 (p = 3 mod 4), "complex" method; returns 1 iff a is a square */
+static int fp2_sqrt(fp2 *r, const fp2 *a) {
+    fp n, t, x0, x1, two_inv, nn;
+    if (fp_is_zero(&a->c1)) {
+        if (fp_sqrt(&x0, &a->c0)) { r->c0 = x0; fp_zero(&r->c1); return 1; }
+        fp_neg(&t, &a->c0);
+        fp_sqrt(&x0, &t);                           /* -a0 is a square when a0 is not */
+        fp_zero(&r->c0); r->c1 = x0;
+        return 1;
+    }
+    fp_sqr(&n, &a->c0);
+    fp_sqr(&t, &a->c1);
+    fp_add(&n, &n, &t);
+    if (!fp_sqrt(&n, &n)) return 0;
+    fp_one(&two_inv); fp_dbl(&two_inv, &two_inv); fp_inv(&two_inv, &two_inv);
+    for (int k = 0; k < 2; k++) {
+        if (k == 0) nn = n; else fp_neg(&nn, &n);
+        fp_add(&t, &a->c0, &nn);
+        fp_mul(&t, &t, &two_inv);
+        if (!fp_sqrt(&x0, &t) || fp_is_zero(&x0)) continue;
+        fp_dbl(&x1, &x0);
+        fp_inv(&x1, &x1);
+        fp_mul(&x1, &x1, &a->c1);
+        fp2 cand = {x0, x1}, chk;
+        fp2_sqr(&chk, &cand);
+        if (fp2_eq(&chk, a)) { *r = cand; return 1; }
+    }
+    return 0;
+}
+
+#define F fp
+#define FN(x) fp_##x
+#define PT g1
+#define SW(name) ((const fp *)ORA_ISO_G1_##name)
+#define SGN0 fp_sgn0
+#define SQRT fp_sqrt
+#define XNUM_N 12
+#define XDEN_N 11
+#define YNUM_N 16
+#define YDEN_N 16
+#include "ora_sswu_tmpl.h"
+#undef F
+#undef FN
+#undef PT
+#undef SW
+#undef SGN0
+#undef SQRT
+#undef XNUM_N
+#undef XDEN_N
+#undef YNUM_N
+#undef YDEN_N
+
+#define F fp2
+#define FN(x) fp2_##x
+#define PT g2
+#define SW(name) ((const fp2 *)ORA_ISO_G2_##name)
+#define SGN0 fp2_sgn0
+#define SQRT fp2_sqrt
+#define XNUM_N 4
+#define XDEN_N 3
+#define YNUM_N 4
+#define YDEN_N 4
+#include "ora_sswu_tmpl.h"
+#undef F
+#undef FN
+#undef PT
+#undef SW
+#undef SGN0
+#undef SQRT
+#undef XNUM_N
+#undef XDEN_N
+#undef YNUM_N
+#undef YDEN_N
+
+EXPORT int oracle_bls12_map_fp_to_g1(uint8_t *out, const uint8_t *in, size_t in_len) {
+    if (in_len != 64) return ORA_INVALID_LENGTH;
+    fp u;
+    if (ora_fp_from_bytes(&u, in) < 0) return ORA_INVALID_ELEMENT;
+    g1_aff a;
+    g1_map_to_curve(&a, &u);
+    g1_jac p;
+    g1_from_affine(&p, &a);
+    g1_mult(&p, &p, (const uint8_t *)ORA_ISO_H_EFF_G1, 64);          /* clear cofactor: h_eff = 1 - z */
+    g1_to_affine(&a, &p);
+    ora_encode_g1(out, &a);
+    return ORA_SUCCESS;
+}
+EXPORT int oracle_bls12_map_fp2_to_g2(uint8_t *out, const uint8_t *in, size_t in_len) {
+    if (in_len != 128) return ORA_INVALID_LENGTH;
+    fp2 u;
+    if (ora_fp2_from_bytes(&u, in) < 0) return ORA_INVALID_ELEMENT;
+    g2_aff a;
+    g2_map_to_curve(&a, &u);
+    g2_jac p;
+    g2_from_affine(&p, &a);
+    g2_mult(&p, &p, (const uint8_t *)ORA_ISO_H_EFF_G2, ORA_ISO_H_EFF_G2_BITS);   /* h_eff = h2 (3 z^2 - 3) */
+    g2_to_affine(&a, &p);
+    ora_encode_g2(out, &a);
     return ORA_SUCCESS;
 }
 

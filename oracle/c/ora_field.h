@@ -128,8 +128,9 @@ static inline int fp_sqrt(fp *r, const fp *a) {
     fp s, t;
     fp_pow(&s, a, ORA_P_PLUS_1_DIV_4, 6);
     fp_sqr(&t, &s);
+    int ok = fp_eq(&t, a);          /* before writing r: r may alias a */
     *r = s;
-    return fp_eq(&t, a);
+    return ok;
 }
 
 /* ---------------------------------------------------------------- Fp2 */

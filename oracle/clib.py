@@ -41,7 +41,7 @@ _OUT_SIZES = {
     "bls12_g1multiexp_naive": 128, "bls12_g1multiexp_bc": 128,
     "bls12_g2add": 256, "bls12_g2mul": 256, "bls12_g2multiexp": 256,
     "bls12_g2multiexp_naive": 256, "bls12_g2multiexp_bc": 256,
-    "bls12_pairing": 32,
+    "bls12_pairing": 32, "bls12_map_fp_to_g1": 128, "bls12_map_fp2_to_g2": 256,
 }
 
 

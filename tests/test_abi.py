@@ -61,7 +61,8 @@ def test_gas_constants_and_functions(X):
 def test_host_single_ops_match_kat(X):
     with open(os.path.join(GOLD, "kat.json")) as f:
         kat = json.load(f)
-    fn = {"g1add": X.g1_add, "g1mul": X.g1_mul, "g2add": X.g2_add, "g2mul": X.g2_mul}
+    fn = {"g1add": X.g1_add, "g1mul": X.g1_mul, "g2add": X.g2_add, "g2mul": X.g2_mul,
+          "map_fp_to_g1": X.map_fp_to_g1, "map_fp2_to_g2": X.map_fp2_to_g2}
     n = 0
     for v in kat:
         if v["op"] in fn:

@@ -18,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle", "pymodel"))
 import bls12_381 as m  # noqa: E402
+import h2c  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 A = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6
@@ -93,6 +94,13 @@ def kat():
                 pr([(ns1, G2)]), pr([(G1, ns2)]), pr([(G1, G2), ((1, 1), ns2)]), pr([(ns1, ns2)]),
                 bytes(383), b""]:
         add("pairing", m.bls12_pairing, inp)
+    for u in [0, 1, 0x156c8a6a2c184569d69a76be144b5cdc5141d2d2ca4fe341f011e25e3969c55ad9e9b9ce2eb833c81a908e5fa4ac5f03, rng.scalar256() % m.P]:
+        add("map_fp_to_g1", h2c.bls12_map_fp_to_g1, m.encode_fp(u))
+    add("map_fp_to_g1", h2c.bls12_map_fp_to_g1, bytes(63))
+    add("map_fp_to_g1", h2c.bls12_map_fp_to_g1, bytes(16) + m.P.to_bytes(48, "big"))
+    for u in [(0, 0), (1, 2), (rng.scalar256() % m.P, rng.scalar256() % m.P)]:
+        add("map_fp2_to_g2", h2c.bls12_map_fp2_to_g2, m.encode_fp(u[0]) + m.encode_fp(u[1]))
+    add("map_fp2_to_g2", h2c.bls12_map_fp2_to_g2, bytes(129))
     return v
 
 
@@ -101,6 +109,8 @@ if __name__ == "__main__":
     with open(os.path.join(OUT, "kat.json"), "w") as f:
         json.dump(kat(), f, indent=0)
     print("kat.json written")
+    if "--kat-only" in sys.argv:
+        sys.exit(0)
     for wl, l2 in [("g1msm", 10), ("g1msm", 16), ("g1msm", 20), ("g2msm", 10), ("g2msm", 16)]:
         with open(os.path.join(OUT, "%s_2p%d.hex" % (wl, l2)), "w") as f:
             f.write(analytic(wl, l2).hex() + "\n")
