@@ -1,0 +1,80 @@
+"""Published EIP-2537 / go-ethereum vectors (tests/golden/eip2537_published.json: provenance in the
+file) against model, oracle and product, and the KAT ingestion harness (tools/run_kat.py) on files
+written in the reference's two formats (CSV: src/test.c:63-72; JSON: go/blst_eip2537_test.go:18-29).
+The multiexp / pairing entries need the GPU and live in the gpu-marked test."""
+import csv
+import json
+import os
+import sys
+
+import pytest
+
+import bls12_381 as m
+import h2c
+from conftest import ROOT, call_x
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import run_kat  # noqa: E402
+
+with open(os.path.join(ROOT, "tests", "golden", "eip2537_published.json")) as f:
+    PUB = json.load(f)["vectors"]
+MODEL = {"g1add": m.bls12_g1add, "g1mul": m.bls12_g1mul, "g1multiexp": m.bls12_g1multiexp, "g2add": m.bls12_g2add,
+         "g2mul": m.bls12_g2mul, "g2multiexp": m.bls12_g2multiexp, "map_fp_to_g1": h2c.bls12_map_fp_to_g1}
+HOST_OPS = {"g1add": "g1_add", "g1mul": "g1_mul", "g2add": "g2_add", "g2mul": "g2_mul", "map_fp_to_g1": "map_fp_to_g1"}
+
+
+def test_published_vectors_model_oracle_product_host(X, clib):
+    for v in PUB:
+        inp, want = bytes.fromhex(v["Input"]), bytes.fromhex(v["Expected"])
+        assert m.call(MODEL[v["op"]], inp) == (0, want), v["Name"]
+        assert clib.call("bls12_" + v["op"], inp) == (0, want), v["Name"]
+        if v["op"] in HOST_OPS:
+            assert call_x(getattr(X, HOST_OPS[v["op"]]), inp) == (0, want), v["Name"]
+
+
+@pytest.mark.gpu
+def test_published_vectors_product_gpu_ops(X):
+    for v in PUB:
+        if v["op"] == "g1multiexp":
+            assert X.g1_multiexp(bytes.fromhex(v["Input"])) == bytes.fromhex(v["Expected"])
+        if v["op"] == "g2multiexp":
+            assert X.g2_multiexp(bytes.fromhex(v["Input"])) == bytes.fromhex(v["Expected"])
+
+
+def test_kat_ingestion_both_reference_formats(tmp_path, X):
+    with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+        kat = json.load(f)
+    host = [v for v in kat if v["op"] in ("g1add", "g2add", "map_fp_to_g1")]
+    # CSV, success file + a failure file with the C harness's expected code
+    with open(tmp_path / "g1_add.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["input", "result"])
+        for v in host:
+            if v["op"] == "g1add" and v["code"] == 0:
+                w.writerow([v["input"], v["output"]])
+    with open(tmp_path / "g1_not_on_curve.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["input", "result"])
+        for v in host:
+            if v["op"] == "g1add" and v["code"] == 1:
+                w.writerow([v["input"], ""])
+    # geth JSON: success + fail-* files
+    js = [{"Input": v["input"], "Expected": v["output"], "Name": "n%d" % i, "Gas": 600, "NoBenchmark": False}
+          for i, v in enumerate(host) if v["op"] == "g2add" and v["code"] == 0]
+    (tmp_path / "blsG2Add.json").write_text(json.dumps(js))
+    fl = [{"Input": v["input"], "ExpectedError": "x", "Name": "f%d" % i}
+          for i, v in enumerate(host) if v["op"] == "g2add" and v["code"] != 0 and v["input"]]
+    (tmp_path / "fail-blsG2Add.json").write_text(json.dumps(fl))
+    (tmp_path / "blsMapG1.json").write_text(json.dumps(
+        [{"Input": v["Input"], "Expected": v["Expected"], "Name": v["Name"]} for v in PUB if v["op"] == "map_fp_to_g1"]))
+    total = 0
+    for name in ["g1_add.csv", "g1_not_on_curve.csv", "blsG2Add.json", "fail-blsG2Add.json", "blsMapG1.json"]:
+        cases = run_kat.load(str(tmp_path / name))
+        ok, bad = run_kat.run(cases, X)
+        assert not bad, (name, bad)
+        total += ok
+    assert total >= 12
+    # a wrong expectation is reported, not swallowed
+    cases = run_kat.load(str(tmp_path / "blsMapG1.json"))
+    cases[0] = cases[0][:3] + (bytes(128), None)
+    assert run_kat.run(cases, X)[1]
