@@ -374,15 +374,25 @@ HD Fp2 sub(const Fp2 &a, const Fp2 &b) { return Fp2{sub(a.c0, b.c0), sub(a.c1, b
 HD Fp2 neg(const Fp2 &a) { return Fp2{neg(a.c0), neg(a.c1)}; }
 HD Fp2 dbl(const Fp2 &a) { return Fp2{dbl(a.c0), dbl(a.c1)}; }
 HD Fp2 conj(const Fp2 &a) { return Fp2{a.c0, neg(a.c1)}; }
+// Fp products as seen from inside the Fp2 bodies: inlined on the device (the Fp2 product itself
+// is the out-of-line unit there, so a nested call per Fp product would only add callee-save
+// spill traffic), the 64-bit host product otherwise.
+HD Fp fp_mul_leaf(const Fp &a, const Fp &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_mul_cols28(a, b);
+#else
+    return fp_mul_limbs64(a, b);
+#endif
+}
 HD Fp2 fp2_mul_body(const Fp2 &a, const Fp2 &b) {
-    Fp t0 = mul(a.c0, b.c0);
-    Fp t1 = mul(a.c1, b.c1);
-    Fp t2 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    Fp t0 = fp_mul_leaf(a.c0, b.c0);
+    Fp t1 = fp_mul_leaf(a.c1, b.c1);
+    Fp t2 = fp_mul_leaf(add(a.c0, a.c1), add(b.c0, b.c1));
     return Fp2{sub(t0, t1), sub(sub(t2, t0), t1)};
 }
 HD Fp2 fp2_sqr_body(const Fp2 &a) {
-    Fp m = mul(a.c0, a.c1);
-    return Fp2{mul(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
+    Fp m = fp_mul_leaf(a.c0, a.c1);
+    return Fp2{fp_mul_leaf(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
 }
 // On the device the Fp2 product and square are out of line as well.  Besides keeping the code
 // objects small this is a correctness guard: with fp_mul_cols28 and everything above it inlined,

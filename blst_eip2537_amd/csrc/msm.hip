@@ -12,8 +12,9 @@
 //   k_msm_tasks    [bucket]  split every bucket into tasks of <= L entries
 //   k_msm_task_*   [task]    counting sort of the tasks by length (equal trip counts per wave)
 //   k_msm_accum    [task]    XYZZ mixed additions over the task's entries        (dominant)
-//   k_msm_reduce   [segment] running-sum sum_j j*B_j over S buckets + offset multiple, then a
-//                            wavefront-shuffle tree and an LDS step -> one point per block
+//   k_msm_reduce1/4 [segment] running-sum sum_j j*B_j over S buckets + offset multiple, then a
+//                            wavefront-shuffle tree and an LDS step -> one point per block;
+//                            G2 spreads every point operation over 4 lanes (k_msm_reduce4)
 //   host                     adds the few per-block points of each window, Horner over windows
 #include <algorithm>
 #include <stdio.h>
@@ -55,7 +56,7 @@ MsmPlan msm_make_plan(uint32_t n, int c_override) {
     }
     MsmPlan &pl = best;
     pl.L = 64;
-    pl.S = pl.c >= 12 ? 16 : (pl.c >= 8 ? 8 : 4);
+    pl.S = 16;                                   // refined per field in msm_device_t
     pl.max_entries = (uint64_t)n * pl.W;
     pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
     return pl;
@@ -274,40 +275,172 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F> &p
     return Xyzz<F>{shfl_down(p.x, off), shfl_down(p.y, off), shfl_down(p.zz, off), shfl_down(p.zzz, off)};
 }
 
+// ---- bucket reduce, 4 lanes per running sum -------------------------------------------------
+// The reduce is a serial chain of ~60 point operations per segment, so it is bound by the
+// latency of one operation, not by throughput.  Every logical thread is therefore a 4-lane
+// group that holds its operands replicated; the independent field products of an XYZZ addition
+// (4 rounds of <= 4) or doubling (3 rounds) are dealt one per lane and exchanged with
+// wavefront shuffles, cutting the chain latency ~3x.
+__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
+    return r;
+}
+__device__ __forceinline__ FpI shfl_from(const FpI &a, int src) { return FpI{shfl_from(a.v, src)}; }
+__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
+template <class T> __device__ __forceinline__ Xyzz<T> shfl_from(const Xyzz<T> &p, int src) {
+    return Xyzz<T>{shfl_from(p.x, src), shfl_from(p.y, src), shfl_from(p.zz, src), shfl_from(p.zzz, src)};
+}
+__device__ __forceinline__ Fp sel4(int r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
+    return o;
+}
+__device__ __forceinline__ FpI sel4(int r, const FpI &a, const FpI &b, const FpI &c, const FpI &d) { return FpI{sel4(r, a.v, b.v, c.v, d.v)}; }
+__device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
+    return Fp2{sel4(r, a.c0, b.c0, c.c0, d.c0), sel4(r, a.c1, b.c1, c.c1, d.c1)};
+}
+
+// P + Q (add-2008-s), operands replicated on the 4 lanes of the group, complete
+template <class T> __device__ __forceinline__ Xyzz<T> add4(const Xyzz<T> &p, const Xyzz<T> &q, int r, int gb) {
+    const bool pinf = is_inf(p), qinf = is_inf(q);            // uniform in the group
+    if (qinf) return p;
+    if (pinf) return q;
+    T pr = mul(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
+    const T U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
+    const T Pd = sub(U2, U1), Rr = sub(S2, S1);
+    if (is_zero(Pd)) {                                         // same x: double or cancel (rare)
+        if (is_zero(Rr)) return dbl(p);
+        return xyzz_inf<T>();
+    }
+    pr = mul(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
+    const T PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
+    pr = mul(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
+    const T PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
+    const T X3 = sub(sub(RR, PPP), dbl(Q));
+    pr = mul(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
+    const T t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
+}
+// 2P (dbl-2008-s-1); infinity stays infinity
+template <class T> __device__ __forceinline__ Xyzz<T> dbl4(const Xyzz<T> &p, int r, int gb) {
+    const T U = dbl(p.y);
+    T pr = mul(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
+    const T V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
+    const T M = add(dbl(XX), XX);
+    pr = mul(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
+    const T W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
+    const T X3 = sub(MM, dbl(S));
+    pr = mul(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
+    const T t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
+}
+template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &p, uint32_t m, int r, int gb) {
+    Xyzz<T> acc = xyzz_inf<T>();
+    for (int i = 31 - __builtin_clz(m | 1u); i >= 0; i--) {
+        acc = dbl4(acc, r, gb);
+        if ((m >> i) & 1u) acc = add4(acc, p, r, gb);
+    }
+    return acc;
+}
+
+// grid (blocks, W); 256 threads = 64 four-lane groups, one segment of S buckets per group
+template <class F>
+__global__ void __launch_bounds__(256, 1)      // latency-bound chain: registers over occupancy
+k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl,
+             Xyzz<F> *__restrict__ winout_) {
+    using T = typename AccumField<F>::T;
+    const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
+    Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
+    const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
+    const uint32_t seg = blockIdx.x * 64u + (threadIdx.x >> 2);
+    const uint32_t lo = seg * pl.S;
+    Xyzz<T> C = xyzz_inf<T>();
+    if (lo < nbw) {                                            // uniform in the group
+        const uint32_t hi = min(lo + pl.S, nbw);
+        Xyzz<T> R = xyzz_inf<T>(), Q = xyzz_inf<T>();
+        for (uint32_t v = hi; v > lo; v--) {
+            const uint32_t g = (uint32_t)w * pl.B + v - 1u;
+            const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+            for (uint32_t t = t0; t < t1; t++) R = add4(R, partial[t], r, gb);
+            Q = add4(Q, R, r, gb);
+        }
+        // sum_{v in (lo, hi]} v * B_v = Q + lo * R
+        C = add4(Q, small_mul4(R, lo, r, gb), r, gb);
+    }
+    // product tree over the 16 groups of the wave, then the 4 waves through LDS
+    for (int off = 4; off < 64; off <<= 1) {
+        Xyzz<T> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 4) C = add4(C, o, r, gb);
+    }
+    __shared__ Xyzz<T> sm[4];
+    if (lane == 0) sm[wave] = C;
+    __syncthreads();
+    if (wave == 0 && lane < 4) {
+        for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
+        if (lane == 0) winout[(size_t)w * gridDim.x + blockIdx.x] = C;
+    }
+}
+
+// ---- bucket reduce, one lane per running sum (used for G1) ------------------------------------
+// Measured at 2^20 / c = 16: 1.55 ms against 1.8-2.1 ms for the 4-lane form above (whose per-round
+// select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
+// products are 3x heavier and the 4-lane form wins 2.2 ms to 7.0 ms at 2^16.
+template <class T> static __device__ __noinline__ void xyzz_add_o(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
+template <class T> static __device__ __noinline__ void xyzz_dbl_o(Xyzz<T> *r, const Xyzz<T> *a) { *r = dbl(*a); }
+
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_reduce(const Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, MsmPlan pl,
-             Xyzz<F> *__restrict__ winout) {
+k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl,
+              Xyzz<F> *__restrict__ winout_) {
+    using T = typename AccumField<F>::T;
+    const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
+    Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
     const int w = blockIdx.y;
     const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
     const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
     const uint32_t lo = seg * pl.S;
-    Xyzz<F> C = xyzz_inf<F>();
+    Xyzz<T> C = xyzz_inf<T>();
     if (lo < nbw) {
         const uint32_t hi = min(lo + pl.S, nbw);
-        Xyzz<F> R = xyzz_inf<F>(), Q = xyzz_inf<F>();
+        Xyzz<T> R = xyzz_inf<T>(), Q = xyzz_inf<T>();
         for (uint32_t v = hi; v > lo; v--) {
             const uint32_t g = (uint32_t)w * pl.B + v - 1u;
             const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
-            for (uint32_t t = t0; t < t1; t++) R = add(R, partial[t]);
-            Q = add(Q, R);
+            for (uint32_t t = t0; t < t1; t++) {
+                Xyzz<T> pt = partial[t];
+                xyzz_add_o<T>(&R, &R, &pt);
+            }
+            xyzz_add_o<T>(&Q, &Q, &R);
         }
         // sum_{v in (lo, hi]} v * B_v = Q + lo * R
-        C = add(Q, small_mul(R, lo));
+        Xyzz<T> m = xyzz_inf<T>();
+        for (int i = 31 - __builtin_clz(lo | 1u); i >= 0; i--) {
+            xyzz_dbl_o<T>(&m, &m);
+            if ((lo >> i) & 1u) xyzz_add_o<T>(&m, &m, &R);
+        }
+        xyzz_add_o<T>(&C, &Q, &m);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int off = 32; off >= 1; off >>= 1) {
-        Xyzz<F> o = shfl_down(C, off);
-        if (lane < off) C = add(C, o);
+        Xyzz<T> o = shfl_from(C, (lane + off) & 63);
+        if (lane < off) xyzz_add_o<T>(&C, &C, &o);
     }
-    __shared__ Xyzz<F> sm[4];
+    __shared__ Xyzz<T> sm[4];
     if (lane == 0) sm[wave] = C;
     __syncthreads();
     if (threadIdx.x == 0) {
-        C = add(add(sm[0], sm[1]), add(sm[2], sm[3]));
+        for (int k = 1; k < 4; k++) xyzz_add_o<T>(&C, &C, &sm[k]);
         winout[(size_t)w * gridDim.x + blockIdx.x] = C;
     }
 }
+
+template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; };
+template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; };
 
 template <class F>
 static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
@@ -319,8 +452,16 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     MsmPlan pl = msm_make_plan((uint32_t)n, c_override);
     if (pl.max_entries >= (1ull << 32)) return E_MEMORY_ERROR;
     const uint32_t lshift = 6;   // L = 64
+    // reduce: a latency-bound serial chain of ~2S + 30 point operations per segment.
+    //  G1: one lane per segment, 256 segments per block, S = 16 (0.5 wave per SIMD at c = 16)
+    //  G2: 4 lanes per segment, 64 segments per block; the shortest chain that still places at
+    //      most one wave on every SIMD (<= ~232 working blocks on 256 CUs: a second wave on a SIMD
+    //      doubles the latency of both and the kernel waits for the slowest)
+    const uint32_t seg_per_block = ReduceCfg<F>::kFourLane ? 64u : 256u;
+    if (ReduceCfg<F>::kFourLane) pl.S = std::max(1u, (pl.NB + 64u * 232u - 1u) / (64u * 232u));
+    else pl.S = pl.c >= 12 ? 16 : (pl.c >= 8 ? 8 : 4);
     const uint32_t seg_per_win = (std::max(pl.B, pl.BT) + pl.S - 1) / pl.S;
-    const uint32_t red_blocks = (seg_per_win + 255u) / 256u;
+    const uint32_t red_blocks = (seg_per_win + seg_per_block - 1u) / seg_per_block;
     const size_t nwin_out = (size_t)pl.W * red_blocks;
 
     HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
@@ -378,7 +519,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipEventRecord(e->ev_a, s));
     hipLaunchKernelGGL(k_msm_accum<F>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL(k_msm_reduce<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
+    if (ReduceCfg<F>::kFourLane)
+        hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
+    else
+        hipLaunchKernelGGL(k_msm_reduce1<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
