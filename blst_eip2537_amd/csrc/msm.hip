@@ -12,6 +12,7 @@
 //   k_msm_tasks    [bucket]  split every bucket into tasks of <= L entries
 //   k_msm_task_*   [task]    counting sort of the tasks by length (equal trip counts per wave)
 //   k_msm_accum    [task]    XYZZ mixed additions over the task's entries        (dominant)
+//   k_msm_fold     [multi-task bucket]  parallel sum of the task partials of split buckets
 //   k_msm_reduce1/4 [segment] running-sum sum_j j*B_j over S buckets + offset multiple, then a
 //                            wavefront-shuffle tree and an LDS step -> one point per block;
 //                            G2 spreads every point operation over 4 lanes (k_msm_reduce4)
@@ -183,13 +184,15 @@ k_msm_scatter(const uint32_t *__restrict__ in, MsmPlan pl, const uint8_t *__rest
 
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
-            const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks) {
+            const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
+            uint32_t *__restrict__ heavy, uint32_t *heavy_count) {
     uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= NB) return;
     uint32_t cnt = counts[g];
     if (!cnt) return;
     uint32_t t0 = taskoff[g], off = offsets[g];
     const uint32_t L = 1u << lshift;
+    if (cnt > L) heavy[atomicAdd(heavy_count, 1u)] = g;        // more than one task: folded by k_msm_fold
     for (uint32_t done = 0, j = 0; done < cnt; done += L, j++)
         tasks[t0 + j] = Task{off + done, min(L, cnt - done)};
 }
@@ -273,6 +276,42 @@ __device__ __forceinline__ Fp shfl_down(const Fp &a, int off) {
 __device__ __forceinline__ Fp2 shfl_down(const Fp2 &a, int off) { return Fp2{shfl_down(a.c0, off), shfl_down(a.c1, off)}; }
 template <class F> __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F> &p, int off) {
     return Xyzz<F>{shfl_down(p.x, off), shfl_down(p.y, off), shfl_down(p.zz, off), shfl_down(p.zzz, off)};
+}
+
+// ---- fold: buckets that were split into several tasks ------------------------------------------
+// A bucket with more than L entries (the top window when it has only a few bits, duplicate-heavy
+// or adversarial inputs: all scalars equal puts every record of a window into ONE bucket) leaves
+// several task partials.  One block per such bucket sums them: 256 strided serial chains, a
+// wavefront-shuffle tree, an LDS step; the total lands in the bucket's first task slot, which is
+// the only one the reduce kernels read.  (Summing them serially inside the reduce cost 93 ms at
+// n = 2^18, where the top window has 1 bit and its two buckets ~2000 tasks each.)
+template <class T> static __device__ __noinline__ void xyzz_add_f(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_fold(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ heavy,
+           const uint32_t *__restrict__ heavy_count) {
+    __shared__ Xyzz<F> sm[4];
+    const uint32_t nh = *heavy_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t g = heavy[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        Xyzz<F> acc = xyzz_inf<F>();
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
+            Xyzz<F> pt = partial[t];
+            xyzz_add_f<F>(&acc, &acc, &pt);
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            Xyzz<F> o = shfl_down(acc, off);
+            if (lane < off) xyzz_add_f<F>(&acc, &acc, &o);
+        }
+        if (lane == 0) sm[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; k++) xyzz_add_f<F>(&acc, &acc, &sm[k]);
+            partial[t0] = acc;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- bucket reduce, 4 lanes per running sum -------------------------------------------------
@@ -366,7 +405,7 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
         for (uint32_t v = hi; v > lo; v--) {
             const uint32_t g = (uint32_t)w * pl.B + v - 1u;
             const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
-            for (uint32_t t = t0; t < t1; t++) R = add4(R, partial[t], r, gb);
+            if (t1 > t0) R = add4(R, partial[t0], r, gb);       // multi-task buckets were folded into slot t0
             Q = add4(Q, R, r, gb);
         }
         // sum_{v in (lo, hi]} v * B_v = Q + lo * R
@@ -411,8 +450,8 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
         for (uint32_t v = hi; v > lo; v--) {
             const uint32_t g = (uint32_t)w * pl.B + v - 1u;
             const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
-            for (uint32_t t = t0; t < t1; t++) {
-                Xyzz<T> pt = partial[t];
+            if (t1 > t0) {                                      // multi-task buckets were folded into slot t0
+                Xyzz<T> pt = partial[t0];
                 xyzz_add_o<T>(&R, &R, &pt);
             }
             xyzz_add_o<T>(&Q, &Q, &R);
@@ -477,13 +516,14 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->scalars.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
+    HIPCHK(e->heavy.reserve((size_t)pl.NB * 4));
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
     hipStream_t s = e->stream;
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
     HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
-    HIPCHK(hipMemsetAsync(totals, 0, 16, s));
+    HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] heavy buckets
     HIPCHK(hipMemsetAsync(e->counts.p, 0, (size_t)pl.NB * 4, s));
     HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)pl.NB * 4, s));
 
@@ -511,7 +551,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, valid, offsets, cursor, entries);
-    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks);
+    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
+                       reinterpret_cast<uint32_t *>(e->heavy.p), totals + 2);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
     hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist);
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
@@ -519,6 +560,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipEventRecord(e->ev_a, s));
     hipLaunchKernelGGL(k_msm_accum<F>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
+    hipLaunchKernelGGL(k_msm_fold<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, reinterpret_cast<const uint32_t *>(e->heavy.p), totals + 2);
     if (ReduceCfg<F>::kFourLane)
         hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
     else

@@ -111,3 +111,35 @@ def test_g2_msm_sharded_equals_whole(X, clib):
     d = _dev(inp)
     parts = [X.dev_call("eip2537_hip_g2msm_partial_dev", d.data_ptr() + s * 1000 * 288, 1000) for s in range(3)]
     assert X.combine("eip2537_hip_g2msm_combine", parts) == whole
+
+
+def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
+    """Sizes whose window plan leaves a 1-3 bit top window (its buckets hold ~n/2 records) and the
+    adversarial all-equal-scalars input (one bucket per window holds everything): multi-task buckets
+    are folded in parallel (k_msm_fold) and must still give the oracle's bytes."""
+    inp = X.gen_msm_input("g1", 1 << 14, A, B, 1414)
+    assert call_x(X.g1_multiexp, inp) == clib.call("bls12_g1multiexp", inp)
+    # 2^18 (c = 15, 1-bit top window): whole == 4 shards of 2^16 (c = 13) == ragged shards
+    n = 1 << 18
+    inp = X.gen_msm_input("g1", n, A, B, 1818)
+    d = _dev(inp)
+    whole = X.dev_call("eip2537_hip_g1multiexp_dev", d.data_ptr(), n)
+    parts = [X.dev_call("eip2537_hip_g1msm_partial_dev", d.data_ptr() + s * (n // 4) * 160, n // 4) for s in range(4)]
+    assert X.combine("eip2537_hip_g1msm_combine", parts) == whole
+    cuts = [0, 5000, 70000, n]
+    parts = [X.dev_call("eip2537_hip_g1msm_partial_dev", d.data_ptr() + lo * 160, hi - lo) for lo, hi in zip(cuts, cuts[1:])]
+    assert X.combine("eip2537_hip_g1msm_combine", parts) == whole
+    # all scalars equal: sum k*P_i = k * sum P_i ; 20000 records, k = 2^256 - 1 and k = 1
+    m20 = 20000
+    base = X.gen_msm_input("g1", m20, A, B, 7)
+    for k in (2 ** 256 - 1, 1, m.R + 5):
+        same = b"".join(base[i * 160:i * 160 + 128] + m.encode_scalar(k) for i in range(m20))
+        got = X.g1_multiexp(same)
+        if k == 1:
+            ones = got
+        assert clib.call("bls12_g1multiexp", same) == (0, got), k
+    assert X.g1_mul(ones + m.encode_scalar(2 ** 256 - 1)) == X.g1_multiexp(
+        b"".join(base[i * 160:i * 160 + 128] + m.encode_scalar(2 ** 256 - 1) for i in range(m20)))
+    # G2 with a heavy top window
+    inp = X.gen_msm_input("g2", 1 << 12, A, B, 1212)
+    assert call_x(X.g2_multiexp, inp) == clib.call("bls12_g2multiexp", inp)
