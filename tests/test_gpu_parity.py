@@ -151,3 +151,28 @@ def test_pairing_error_order(X, clib):
     assert call_x(X.pairing, bytes(t)) == (2, None)
     assert call_x(X.pairing, b"") == (5, None)
     assert call_x(X.pairing, bytes(383)) == (5, None)
+
+
+def test_concurrent_callers_are_serialised_correctly(X, clib):
+    """The ABI is stateless and callers may be concurrent (cargo test threads, goroutines --
+    SURVEY.md 8b): eight threads hammer different precompiles through one engine."""
+    import threading
+    g1 = [clib.gen_msm_input("g1", 100 + 37 * t, A, B, 1000 + t) for t in range(4)]
+    g2 = [clib.gen_msm_input("g2", 40 + 11 * t, A, B, 2000 + t) for t in range(2)]
+    pr = [_pairs([(m.g1_mul(m.G1, 3 + t), m.G2), (m.ec_neg(m.FP, m.G1), m.g2_mul(m.G2, 3 + t))]) for t in range(2)]
+    want = [clib.call("bls12_g1multiexp", b) for b in g1] + [clib.call("bls12_g2multiexp", b) for b in g2] + \
+           [clib.call("bls12_pairing", b) for b in pr]
+    jobs = [(X.g1_multiexp, b) for b in g1] + [(X.g2_multiexp, b) for b in g2] + [(X.pairing, b) for b in pr]
+    bad = []
+
+    def work(i):
+        fn, inp = jobs[i]
+        for _ in range(6):
+            if call_x(fn, inp) != want[i]:
+                bad.append(i)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not bad
