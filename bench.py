@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--workload", choices=["g1msm", "g2msm", "pairing"], default="g1msm")
     ap.add_argument("--log2n", type=int, default=None, help="log2 of the batch (default 20 / 16 / 12)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
+    ap.add_argument("--window", type=int, default=0, help="force the Pippenger window width (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -109,6 +110,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     X.init(dev_index)
+    if args.window:
+        X.set_window(args.window)
 
     wl = args.workload
     log2n = args.log2n if args.log2n is not None else {"g1msm": 20, "g2msm": 16, "pairing": 12}[wl]

@@ -12,7 +12,7 @@
 //   k_msm_tasks    [bucket]  split every bucket into tasks of <= L entries
 //   k_msm_task_*   [task]    counting sort of the tasks by length (equal trip counts per wave)
 //   k_msm_accum    [task]    XYZZ mixed additions over the task's entries        (dominant)
-//   k_msm_fold     [multi-task bucket]  parallel sum of the task partials of split buckets
+//   k_msm_fold_*   [split bucket]  sum of the task partials of buckets split into several tasks
 //   k_msm_reduce1/4 [segment] running-sum sum_j j*B_j over S buckets + offset multiple, then a
 //                            wavefront-shuffle tree and an LDS step -> one point per block;
 //                            G2 spreads every point operation over 4 lanes (k_msm_reduce4)
@@ -47,6 +47,10 @@ MsmPlan msm_make_plan(uint32_t n, int c_override) {
         pl.c = c;
         pl.W = (256 + c - 1) / c;
         pl.topbits = 256 - (pl.W - 1) * c;
+        // a top window of only a few bits would put ~n/2 records into each of its buckets (split
+        // buckets, same-address atomics): let it absorb the window below instead
+        if (pl.topbits < 8 && pl.W > 1) { pl.W -= 1; pl.topbits += c; }
+        if (pl.topbits > 18) continue;
         pl.B = 1u << (c - 1);
         pl.BT = 1u << pl.topbits;
         pl.NB = (uint32_t)(pl.W - 1) * pl.B + pl.BT;
@@ -56,7 +60,7 @@ MsmPlan msm_make_plan(uint32_t n, int c_override) {
         if (cost < best_cost) { best_cost = cost; best = pl; }
     }
     MsmPlan &pl = best;
-    pl.L = 64;
+    pl.L = 64;                                   // refined in msm_device_t
     pl.S = 16;                                   // refined per field in msm_device_t
     pl.max_entries = (uint64_t)n * pl.W;
     pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
@@ -65,7 +69,8 @@ MsmPlan msm_make_plan(uint32_t n, int c_override) {
 
 // Signed window digits of an unreduced 256-bit scalar.  Windows 0..W-2 are signed with digits in
 // [-(B-1)..B]; the top window is unsigned and absorbs the last carry (value <= 2^topbits), so no
-// extra carry window exists.  fn(global bucket id, negate).
+// extra carry window exists.  fn(global bucket id, negate, digit != 0) is called for EVERY window on
+// every lane, so that the callers' wave-level ballots and shuffles stay converged.
 template <class Fn>
 __device__ __forceinline__ void for_each_digit(const uint32_t k[8], const MsmPlan &pl, Fn &&fn) {
     uint32_t s[8];
@@ -82,32 +87,66 @@ __device__ __forceinline__ void for_each_digit(const uint32_t k[8], const MsmPla
         uint32_t ng = d > pl.B ? 1u : 0u;
         if (ng) d = (mask + 1u) - d;
         carry = ng;
-        if (d) fn((uint32_t)w * pl.B + d - 1u, ng);
+        fn((uint32_t)w * pl.B + d - 1u, ng, d != 0u);
     }
     uint32_t d = s[0] + carry;
-    if (d) fn((uint32_t)(pl.W - 1) * pl.B + d - 1u, 0u);
+    fn((uint32_t)(pl.W - 1) * pl.B + d - 1u, 0u, d != 0u);
+}
+
+
+// Bucket counter update for one digit of every active lane.  Ordinary inputs have 64 different
+// buckets per wave and take the plain atomic; when neighbouring lanes hit the same bucket
+// (degenerate inputs: equal scalars, tiny windows) same-address atomics serialise (~12 ns each),
+// so such waves elect one lane per distinct bucket to add the whole multiplicity.
+// Returns this lane's rank within its bucket's reservation (old value + rank).
+__device__ __forceinline__ uint32_t bucket_atomic_add(uint32_t *counters, uint32_t g, bool active_lane) {
+    const unsigned long long act = __ballot(active_lane);
+    const int lane = threadIdx.x & 63;
+    const uint32_t gn = __shfl(g, (lane + 1) & 63, 64);
+    const unsigned long long dup = __ballot(active_lane && gn == g) & (act >> 1 | act << 63);
+    uint32_t res = 0;
+    if (__popcll(dup) < 8) {
+        if (active_lane) res = atomicAdd(&counters[g], 1u);
+        return res;
+    }
+    unsigned long long todo = act;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t gl = __shfl(g, leader, 64);
+        const unsigned long long same = __ballot(active_lane && g == gl) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counters[gl], (uint32_t)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (active_lane && g == gl) res = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return res;
 }
 
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts,
              uint8_t *__restrict__ valid, uint32_t *__restrict__ counts, unsigned long long *err) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= pl.n) return;
-    const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords;
-    Aff<F> a;
-    int st = decode_point<F>(a, w);
-    if (st != E_SUCCESS) {
-        atomicMin(err, ((unsigned long long)i << 3) | (unsigned long long)st);
-        valid[i] = 0;
-        return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool live = false;
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < pl.n) {
+        const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords;
+        Aff<F> a;
+        int st = decode_point<F>(a, w);
+        if (st != E_SUCCESS) {
+            atomicMin(err, ((unsigned long long)i << 3) | (unsigned long long)st);
+            valid[i] = 0;
+        } else if (is_inf(a)) {
+            valid[i] = 0;
+        } else {
+            pts[i] = a;
+            valid[i] = 1;
+            live = true;
+            decode_scalar(k, w + Wire<F>::kPointWords);
+        }
     }
-    if (is_inf(a)) { valid[i] = 0; return; }
-    pts[i] = a;
-    valid[i] = 1;
-    uint32_t k[8];
-    decode_scalar(k, w + Wire<F>::kPointWords);
-    for_each_digit(k, pl, [&](uint32_t g, uint32_t) { atomicAdd(&counts[g], 1u); });
+    for_each_digit(k, pl, [&](uint32_t g, uint32_t, bool nz) { bucket_atomic_add(counts, g, live && nz); });
 }
 
 // Three-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
@@ -171,28 +210,30 @@ __global__ void __launch_bounds__(256)
 k_msm_scatter(const uint32_t *__restrict__ in, MsmPlan pl, const uint8_t *__restrict__ valid,
               const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
               uint32_t *__restrict__ entries) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= pl.n || !valid[i]) return;
-    const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords + Wire<F>::kPointWords;
-    uint32_t k[8];
-    decode_scalar(k, w);
-    for_each_digit(k, pl, [&](uint32_t g, uint32_t ng) {
-        uint32_t pos = offsets[g] + atomicAdd(&cursor[g], 1u);
-        entries[pos] = (i << 1) | ng;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool live = i < pl.n && valid[i];
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) decode_scalar(k, in + (size_t)i * Wire<F>::kMsmRecWords + Wire<F>::kPointWords);
+    for_each_digit(k, pl, [&](uint32_t g, uint32_t ng, bool nz) {
+        const uint32_t rank = bucket_atomic_add(cursor, g, live && nz);
+        if (live && nz) entries[offsets[g] + rank] = (i << 1) | ng;
     });
 }
 
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
-            uint32_t *__restrict__ heavy, uint32_t *heavy_count) {
+            uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts) {
     uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= NB) return;
     uint32_t cnt = counts[g];
     if (!cnt) return;
     uint32_t t0 = taskoff[g], off = offsets[g];
     const uint32_t L = 1u << lshift;
-    if (cnt > L) heavy[atomicAdd(heavy_count, 1u)] = g;        // more than one task: folded by k_msm_fold
+    // buckets split into several tasks are folded back into one partial before the reduce:
+    // 2..8 tasks by one thread (k_msm_fold_small), more by one block (k_msm_fold_big)
+    if (cnt > 8u * L) split_big[atomicAdd(&split_counts[1], 1u)] = g;
+    else if (cnt > L) split_small[atomicAdd(&split_counts[0], 1u)] = g;
     for (uint32_t done = 0, j = 0; done < cnt; done += L, j++)
         tasks[t0 + j] = Task{off + done, min(L, cnt - done)};
 }
@@ -200,15 +241,15 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
 
 // Tasks sorted by length, longest first: bucket loads are Poisson distributed, so without this
 // a wave of k_msm_accum runs for the longest of its 64 tasks (~70 % lane utilisation at 2^20).
-// Counting sort on len in [1, 64]: per-block LDS histogram -> 64 global counters -> a one-wave
+// Counting sort on the length class ceil(len / (L/64)) in [1, 64]: per-block LDS histogram -> 64 global counters -> a one-wave
 // scan -> per-block range reservation -> permutation.
 __global__ void __launch_bounds__(256)
-k_msm_task_hist(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenhist) {
+k_msm_task_hist(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenhist, uint32_t gshift) {
     __shared__ uint32_t h[65];
     if (threadIdx.x < 65) h[threadIdx.x] = 0;
     __syncthreads();
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t < totals[1]) atomicAdd(&h[tasks[t].len], 1u);
+    if (t < totals[1]) atomicAdd(&h[(tasks[t].len + (1u << gshift) - 1u) >> gshift], 1u);   // length class 1..64
     __syncthreads();
     if (threadIdx.x < 65 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
 }
@@ -226,13 +267,13 @@ k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ len
 }
 __global__ void __launch_bounds__(256)
 k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenoff,
-                uint32_t *__restrict__ perm) {
+                uint32_t *__restrict__ perm, uint32_t gshift) {
     __shared__ uint32_t h[65], base[65];
     if (threadIdx.x < 65) h[threadIdx.x] = 0;
     __syncthreads();
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     uint32_t len = 0, local = 0;
-    if (t < totals[1]) { len = tasks[t].len; local = atomicAdd(&h[len], 1u); }
+    if (t < totals[1]) { len = (tasks[t].len + (1u << gshift) - 1u) >> gshift; local = atomicAdd(&h[len], 1u); }
     __syncthreads();
     if (threadIdx.x < 65 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&lenoff[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
@@ -281,20 +322,37 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F> &p
 // ---- fold: buckets that were split into several tasks ------------------------------------------
 // A bucket with more than L entries (the top window when it has only a few bits, duplicate-heavy
 // or adversarial inputs: all scalars equal puts every record of a window into ONE bucket) leaves
-// several task partials.  One block per such bucket sums them: 256 strided serial chains, a
-// wavefront-shuffle tree, an LDS step; the total lands in the bucket's first task slot, which is
-// the only one the reduce kernels read.  (Summing them serially inside the reduce cost 93 ms at
-// n = 2^18, where the top window has 1 bit and its two buckets ~2000 tasks each.)
+// several task partials.  They are summed into the bucket's first task slot, the only one the
+// reduce kernels read.  (Summing them serially inside the reduce cost 93 ms at n = 2^18, where the
+// top window has 1 bit and its two buckets ~2000 tasks each; a block per split bucket cost 30 ms
+// when most buckets had 2-4 tasks -- hence two tiers, and L grows with the mean bucket load.)
 template <class T> static __device__ __noinline__ void xyzz_add_f(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
+// 2..8 tasks: one thread per bucket
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_fold(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ heavy,
-           const uint32_t *__restrict__ heavy_count) {
+k_msm_fold_small(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+                 const uint32_t *__restrict__ split_counts) {
+    const uint32_t n = split_counts[0];
+    for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < n; h += gridDim.x * 256u) {
+        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        Xyzz<F> acc = partial[t0];
+        for (uint32_t t = t0 + 1; t < t1; t++) {
+            Xyzz<F> pt = partial[t];
+            xyzz_add_f<F>(&acc, &acc, &pt);
+        }
+        partial[t0] = acc;
+    }
+}
+// more than 8 tasks: one block per bucket -- 256 strided serial chains, shuffle tree, LDS step
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_fold_big(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+               const uint32_t *__restrict__ split_counts) {
     __shared__ Xyzz<F> sm[4];
-    const uint32_t nh = *heavy_count;
+    const uint32_t nh = split_counts[1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-        const uint32_t g = heavy[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
         Xyzz<F> acc = xyzz_inf<F>();
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
             Xyzz<F> pt = partial[t];
@@ -490,7 +548,13 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     MsmPlan pl = msm_make_plan((uint32_t)n, c_override);
     if (pl.max_entries >= (1ull << 32)) return E_MEMORY_ERROR;
-    const uint32_t lshift = 6;   // L = 64
+    // task length limit L = 2^lshift: at least 64, and at least twice the mean bucket load so that
+    // split buckets stay the exception (they cost an extra fold pass)
+    uint32_t lshift = 6;
+    while (lshift < 20 && (1ull << lshift) < 2ull * n / pl.B) lshift++;
+    const uint32_t gshift = lshift - 6;           // granularity of the 64 task-length classes
+    pl.L = 1u << lshift;
+    pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
     // reduce: a latency-bound serial chain of ~2S + 30 point operations per segment.
     //  G1: one lane per segment, 256 segments per block, S = 16 (0.5 wave per SIMD at c = 16)
     //  G2: 4 lanes per segment, 64 segments per block; the shortest chain that still places at
@@ -516,14 +580,14 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->scalars.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
-    HIPCHK(e->heavy.reserve((size_t)pl.NB * 4));
+    HIPCHK(e->heavy.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
     hipStream_t s = e->stream;
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
     HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
-    HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] heavy buckets
+    HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] lightly split [3] heavily split
     HIPCHK(hipMemsetAsync(e->counts.p, 0, (size_t)pl.NB * 4, s));
     HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)pl.NB * 4, s));
 
@@ -546,21 +610,23 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *blk = reinterpret_cast<uint32_t *>(e->scalars.p);
     uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
+    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->heavy.p), *split_big = split_small + pl.NB;
     HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, valid, offsets, cursor, entries);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       reinterpret_cast<uint32_t *>(e->heavy.p), totals + 2);
+                       split_small, split_big, totals + 2);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist);
+    hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist, gshift);
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
-    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
     hipLaunchKernelGGL(k_msm_accum<F>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL(k_msm_fold<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, reinterpret_cast<const uint32_t *>(e->heavy.p), totals + 2);
+    hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
+    hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
     if (ReduceCfg<F>::kFourLane)
         hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
     else
