@@ -40,7 +40,7 @@ PART = {"g1msm": "eip2537_hip_g1msm_partial_dev", "g2msm": "eip2537_hip_g2msm_pa
 COMB = {"g1msm": "eip2537_hip_g1msm_combine", "g2msm": "eip2537_hip_g2msm_combine",
         "pairing": "eip2537_hip_pairing_combine"}
 ORACLE = {"g1msm": "bls12_g1multiexp", "g2msm": "bls12_g2multiexp", "pairing": "bls12_pairing"}
-KERNEL = {"g1msm": "k_msm_accum<Fp>", "g2msm": "k_msm_accum<Fp2>", "pairing": "k_pair_lines"}
+KERNEL = {"g1msm": "k_msm_accum<Fp>", "g2msm": "k_msm_accum2", "pairing": "k_pair_lines"}
 
 
 def seed_for(workload, log2n):

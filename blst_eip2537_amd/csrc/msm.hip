@@ -280,6 +280,83 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
     if (len) perm[base[len] + local] = t;
 }
 
+// ---- wavefront shuffles / selects of field elements (lane-group kernels)
+__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
+    return r;
+}
+__device__ __forceinline__ FpI shfl_from(const FpI &a, int src) { return FpI{shfl_from(a.v, src)}; }
+__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
+template <class T> __device__ __forceinline__ Xyzz<T> shfl_from(const Xyzz<T> &p, int src) {
+    return Xyzz<T>{shfl_from(p.x, src), shfl_from(p.y, src), shfl_from(p.zz, src), shfl_from(p.zzz, src)};
+}
+__device__ __forceinline__ Fp sel4(int r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
+    return o;
+}
+__device__ __forceinline__ FpI sel4(int r, const FpI &a, const FpI &b, const FpI &c, const FpI &d) { return FpI{sel4(r, a.v, b.v, c.v, d.v)}; }
+__device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
+    return Fp2{sel4(r, a.c0, b.c0, c.c0, d.c0), sel4(r, a.c1, b.c1, c.c1, d.c1)};
+}
+
+// ---- G2 accumulate, 2 lanes per task ----------------------------------------------------------
+// Over Fp2 a one-lane mixed addition keeps ~15 Fp2 values live (256 VGPR + 191 AGPR + scratch,
+// one wave per SIMD) and ran at a fifth of the G1 kernel's product rate.  Here a task owns two
+// lanes: the ten products of madd-2008-s are dealt two per round in five rounds
+//   [U2 S2] [PP RR] [PPP Q] [ZZ3 Y1*PPP] [R*(Q-X3) ZZZ3]
+// (every lane busy in every round), halving the chain and doubling the waves.
+__device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
+    Fp2 o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        o.c0.l[i] = r == 0 ? a.c0.l[i] : b.c0.l[i];
+        o.c1.l[i] = r == 0 ? a.c1.l[i] : b.c1.l[i];
+    }
+    return o;
+}
+__device__ __forceinline__ Xyzz<Fp2> madd2(const Xyzz<Fp2> &p, const Aff<Fp2> &q, int r, int gb) {
+    if (is_inf(q)) return p;                                   // uniform in the pair of lanes
+    if (is_inf(p)) return Xyzz<Fp2>{q.x, q.y, fp2_one(), fp2_one()};
+    Fp2 pr = mul(sel2(r, q.x, q.y), sel2(r, p.zz, p.zzz));
+    const Fp2 U2 = shfl_from(pr, gb), S2 = shfl_from(pr, gb + 1);
+    const Fp2 Pd = sub(U2, p.x), Rr = sub(S2, p.y);
+    if (is_zero(Pd)) {
+        if (is_zero(Rr)) return dbl_affine(q);
+        return xyzz_inf<Fp2>();
+    }
+    pr = mul(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
+    const Fp2 PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1);
+    pr = mul(sel2(r, Pd, p.x), PP);
+    const Fp2 PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1);
+    const Fp2 X3 = sub(sub(RR, PPP), dbl(Q));
+    pr = mul(sel2(r, p.zz, p.y), sel2(r, PP, PPP));
+    const Fp2 ZZ3 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1);
+    pr = mul(sel2(r, Rr, p.zzz), sel2(r, sub(Q, X3), PPP));
+    const Fp2 t0 = shfl_from(pr, gb), ZZZ3 = shfl_from(pr, gb + 1);
+    return Xyzz<Fp2>{X3, sub(t0, t1), ZZ3, ZZZ3};
+}
+__global__ void __launch_bounds__(256)
+k_msm_accum2(const Aff<Fp2> *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
+             const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp2> *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, r = lane & 1, gb = lane & ~1;
+    const uint32_t slot = blockIdx.x * 128u + (threadIdx.x >> 1);
+    if (slot >= totals[1]) return;                             // uniform in the pair
+    const uint32_t t = perm[slot];
+    Task tk = tasks[t];
+    Xyzz<Fp2> acc = xyzz_inf<Fp2>();
+    for (uint32_t e = 0; e < tk.len; e++) {
+        uint32_t ent = entries[tk.start + e];
+        Aff<Fp2> p = pts[ent >> 1];
+        if (ent & 1u) p.y = neg(p.y);
+        acc = madd2(acc, p, r, gb);
+    }
+    if (r == 0) partial[t] = acc;
+}
+
 // field type the accumulate loop computes in: Fp -> FpI (inlined products), Fp2 unchanged
 template <class F> struct AccumField { using T = F; };
 template <> struct AccumField<Fp> { using T = FpI; };
@@ -378,28 +455,6 @@ k_msm_fold_big(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ tasko
 // group that holds its operands replicated; the independent field products of an XYZZ addition
 // (4 rounds of <= 4) or doubling (3 rounds) are dealt one per lane and exchanged with
 // wavefront shuffles, cutting the chain latency ~3x.
-__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
-    return r;
-}
-__device__ __forceinline__ FpI shfl_from(const FpI &a, int src) { return FpI{shfl_from(a.v, src)}; }
-__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
-template <class T> __device__ __forceinline__ Xyzz<T> shfl_from(const Xyzz<T> &p, int src) {
-    return Xyzz<T>{shfl_from(p.x, src), shfl_from(p.y, src), shfl_from(p.zz, src), shfl_from(p.zzz, src)};
-}
-__device__ __forceinline__ Fp sel4(int r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
-    Fp o;
-#pragma unroll
-    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
-    return o;
-}
-__device__ __forceinline__ FpI sel4(int r, const FpI &a, const FpI &b, const FpI &c, const FpI &d) { return FpI{sel4(r, a.v, b.v, c.v, d.v)}; }
-__device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
-    return Fp2{sel4(r, a.c0, b.c0, c.c0, d.c0), sel4(r, a.c1, b.c1, c.c1, d.c1)};
-}
-
 // P + Q (add-2008-s), operands replicated on the 4 lanes of the group, complete
 template <class T> __device__ __forceinline__ Xyzz<T> add4(const Xyzz<T> &p, const Xyzz<T> &q, int r, int gb) {
     const bool pinf = is_inf(p), qinf = is_inf(q);            // uniform in the group
@@ -536,6 +591,14 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     }
 }
 
+static void launch_accum(hipStream_t s, uint32_t task_blocks, const Aff<Fp> *pts, const uint32_t *entries, const Task *tasks,
+                         const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
+    hipLaunchKernelGGL(k_msm_accum<Fp>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+}
+static void launch_accum(hipStream_t s, uint32_t task_blocks, const Aff<Fp2> *pts, const uint32_t *entries, const Task *tasks,
+                         const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
+    hipLaunchKernelGGL(k_msm_accum2, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+}
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; };
 template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; };
 
@@ -623,7 +686,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    hipLaunchKernelGGL(k_msm_accum<F>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    launch_accum(s, task_blocks, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
     hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
