@@ -80,14 +80,14 @@ __device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2
 }
 // same result as miller_dbl_step (pairing.h), products dealt over the 4 lanes of the group
 __device__ __forceinline__ Line miller_dbl_step4(MillerT &T, int r, int gbase) {
-    Fp2 pr = mul(sel4(r, T.x, T.y, T.z, T.y), sel4(r, T.x, T.y, T.z, T.z));
+    Fp2 pr = fp2_mul_body(sel4(r, T.x, T.y, T.z, T.y), sel4(r, T.x, T.y, T.z, T.z));   // inlined: hot loop
     const Fp2 A = shfl_from(pr, gbase), B = shfl_from(pr, gbase + 1), ZZ = shfl_from(pr, gbase + 2), YZ = shfl_from(pr, gbase + 3);
     const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
-    pr = mul(sel4(r, B, XB, E, E), sel4(r, B, XB, E, T.x));
+    pr = fp2_mul_body(sel4(r, B, XB, E, E), sel4(r, B, XB, E, T.x));
     const Fp2 C = shfl_from(pr, gbase), t = shfl_from(pr, gbase + 1), F = shfl_from(pr, gbase + 2), EX = shfl_from(pr, gbase + 3);
     const Fp2 D = dbl(sub(sub(t, A), C));
     const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
-    pr = mul(sel4(r, E, Z3, E, E), sel4(r, ZZ, ZZ, sub(D, X3), ZZ));
+    pr = fp2_mul_body(sel4(r, E, Z3, E, E), sel4(r, ZZ, ZZ, sub(D, X3), ZZ));
     const Fp2 EZ = shfl_from(pr, gbase), Z3ZZ = shfl_from(pr, gbase + 1), Ym = shfl_from(pr, gbase + 2);
     Line l;
     l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
@@ -99,9 +99,9 @@ __device__ __forceinline__ Line miller_dbl_step4(MillerT &T, int r, int gbase) {
     return l;
 }
 // scale (a1, a4) by (xP, yP): four Fp products, one per lane; then lanes 0..2 store a0, a1, a4
-__device__ __forceinline__ void store_line4(LineRec *dst, const Line &l, const Aff<Fp> &P, bool contributes, int r, int gbase) {
+__device__ __forceinline__ void store_line4(LineRec *dst, const Line &l, const Aff<Fp> *P, bool contributes, int r, int gbase) {
     Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
-    Fp q = mul(w, r < 2 ? P.x : P.y);
+    Fp q = mul(w, r < 2 ? P->x : P->y);
     Fp2 a1{shfl_from(q, gbase), shfl_from(q, gbase + 1)}, a4{shfl_from(q, gbase + 2), shfl_from(q, gbase + 3)};
     Fp2 v = r == 0 ? l.a0 : (r == 1 ? a1 : a4);
     if (!contributes) v = r == 0 ? fp2_one() : fp2_zero();
@@ -110,16 +110,27 @@ __device__ __forceinline__ void store_line4(LineRec *dst, const Line &l, const A
 
 __global__ void __launch_bounds__(64)
 k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
-    const int lane = threadIdx.x & 63, r = lane & 3, gbase = lane & ~3;
+    // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
+    // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
+    __shared__ Aff<Fp> sP[16];
+    __shared__ Aff<Fp2> sQ[16];
+    const int lane = threadIdx.x & 63, r = lane & 3, gbase = lane & ~3, gi = lane >> 2;
     const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
-    if (i >= k) return;                       // uniform within a 4-lane group
-    Aff<Fp> P;
-    Aff<Fp2> Q;
-    int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
-    int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
-    if (s2 != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
-    const bool q_live = s2 == E_SUCCESS && !is_inf(Q);
-    const bool contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
+    bool q_live = false, contributes = false;
+    MillerT T;
+    if (i < k) {                              // uniform within a 4-lane group
+        Aff<Fp> P;
+        Aff<Fp2> Q;
+        int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
+        int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
+        if (s2 != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
+        q_live = s2 == E_SUCCESS && !is_inf(Q);
+        contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
+        if (r == 0) { sP[gi] = P; sQ[gi] = Q; }
+        T = MillerT{Q.x, Q.y, fp2_one()};
+    }
+    __syncthreads();
+    if (i >= k) return;
     if (!q_live) {
         if (r < 3) {
             Fp2 v = r == 0 ? fp2_one() : fp2_zero();
@@ -127,21 +138,22 @@ k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ 
         }
         return;
     }
-    MillerT T{Q.x, Q.y, fp2_one()};
     const uint64_t z = K_Z_ABS;
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
         Line l = miller_dbl_step4(T, r, gbase);
-        store_line4(&lines[(size_t)s * k + i], l, P, contributes, r, gbase);
+        store_line4(&lines[(size_t)s * k + i], l, &sP[gi], contributes, r, gbase);
         s++;
         if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the 4 lanes
+            Aff<Fp2> Q = sQ[gi];
             l = miller_add_step(T, Q);
-            store_line4(&lines[(size_t)s * k + i], l, P, contributes, r, gbase);
+            store_line4(&lines[(size_t)s * k + i], l, &sP[gi], contributes, r, gbase);
             s++;
         }
     }
     // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T
     //   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
+    Aff<Fp2> Q = sQ[gi];
     Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
     Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
     Fp2 zz = sqr(T.z);
