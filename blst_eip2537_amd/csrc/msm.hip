@@ -619,13 +619,14 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     pl.L = 1u << lshift;
     pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
     // reduce: a latency-bound serial chain of ~2S + 30 point operations per segment.
-    //  G1: one lane per segment, 256 segments per block, S = 16 (0.5 wave per SIMD at c = 16)
+    //  G1: one lane per segment, 256 segments per block
     //  G2: 4 lanes per segment, 64 segments per block; the shortest chain that still places at
     //      most one wave on every SIMD (<= ~232 working blocks on 256 CUs: a second wave on a SIMD
     //      doubles the latency of both and the kernel waits for the slowest)
     const uint32_t seg_per_block = ReduceCfg<F>::kFourLane ? 64u : 256u;
     if (ReduceCfg<F>::kFourLane) pl.S = std::max(1u, (pl.NB + 64u * 232u - 1u) / (64u * 232u));
-    else pl.S = pl.c >= 12 ? 16 : (pl.c >= 8 ? 8 : 4);
+    else pl.S = std::max(2u, (pl.NB + 256u * 140u - 1u) / (256u * 140u));   // ~140 working blocks (0.5 wave/SIMD):
+                                                                            // measured optimum, more waves contend on stack traffic
     const uint32_t seg_per_win = (std::max(pl.B, pl.BT) + pl.S - 1) / pl.S;
     const uint32_t red_blocks = (seg_per_win + seg_per_block - 1u) / seg_per_block;
     const size_t nwin_out = (size_t)pl.W * red_blocks;
