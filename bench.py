@@ -225,6 +225,19 @@ def main():
                          "algorithmic_bytes_per_unit": REC[wl], "units_per_launch": n_local,
                          "note": "integer-VALU-bound by construction (SURVEY.md 8d): the HBM fraction is reported because the metric asks for it"},
         }
+        # the roof this path actually lives under: Fp products per second of the dominant kernel against
+        # the bare product-chain rate of the same v_mad_u64_u32 code (profiles/r01_fpmul_bench.txt)
+        if wl in ("g1msm", "g2msm") and k_ms > 0:
+            c_plan = {20: 16, 16: 13}.get(log2n)
+            windows = None if c_plan is None else (256 + c_plan - 1) // c_plan
+            if windows is not None and 256 - (windows - 1) * c_plan < 8:
+                windows -= 1
+            if windows is not None:
+                prods = n_local * windows * (10 if wl == "g1msm" else 30)      # 8M+2S per mixed addition; Fp2 = 3 Fp
+                result["roofline_valu"] = {"bound": "valu (v_mad_u64_u32 issue)", "kernel": KERNEL[wl],
+                                           "achieved": prods / (k_ms * 1e-3) / 1e9, "peak": 64.7, "unit": "G Fp-products/s",
+                                           "frac": prods / (k_ms * 1e-3) / 1e9 / 64.7,
+                                           "note": "algorithmic products = records x windows x 10 (x3 over Fp2); peak = measured chip-wide rate of the shipped product in isolation (profiles/r01_fpmul_bench.txt, V2)"}
 
     # ---- CPU baseline: oracle restatement of the reference path, 1 thread, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
