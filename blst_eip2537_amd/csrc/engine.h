@@ -20,7 +20,7 @@ struct Engine {
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr;
     // staging + workspace
-    DevBuf input, pts, valid, counts, offsets, cursor, taskoff, entries, tasks, partial, winout, scalars, misc, perm, heavy;
+    DevBuf input, input2, pts, valid, counts, offsets, cursor, taskoff, entries, tasks, partial, winout, scalars, misc, perm, heavy;
     void *host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     // last-call kernel timing (ms), filled when timing is enabled

@@ -6,9 +6,10 @@
 //
 // Pipeline (all kernels on one stream; one thread per unit named in brackets):
 //   k_msm_decode   [record]  wire decode + validation + Montgomery form; AoS affine points;
-//                            signed c-bit window digits -> bucket histogram
+//                            signed c-bit window digits -> digit array [window][record]
+//   k_msm_hist / k_msm_slicescan  per-(slice, window) LDS histograms, scanned over slices
 //   k_msm_scan     [1 block] exclusive scan of the histogram -> entry offsets, task offsets
-//   k_msm_scatter  [record]  counting-sort scatter of (point index, sign) by bucket
+//   k_msm_scatter  [slice x window]  counting-sort scatter of (point index, sign) by bucket, ranks by LDS atomics
 //   k_msm_tasks    [bucket]  split every bucket into tasks of <= L entries
 //   k_msm_task_*   [task]    counting sort of the tasks by length (equal trip counts per wave)
 //   k_msm_accum    [task]    XYZZ mixed additions over the task's entries        (dominant)
@@ -50,7 +51,7 @@ MsmPlan msm_make_plan(uint32_t n, int c_override) {
         // a top window of only a few bits would put ~n/2 records into each of its buckets (split
         // buckets, same-address atomics): let it absorb the window below instead
         if (pl.topbits < 8 && pl.W > 1) { pl.W -= 1; pl.topbits += c; }
-        if (pl.topbits > 18) continue;
+        if (pl.topbits > 16) continue;          // LDS histogram: 65536 packed 16-bit counters
         pl.B = 1u << (c - 1);
         pl.BT = 1u << pl.topbits;
         pl.NB = (uint32_t)(pl.W - 1) * pl.B + pl.BT;
@@ -94,39 +95,10 @@ __device__ __forceinline__ void for_each_digit(const uint32_t k[8], const MsmPla
 }
 
 
-// Bucket counter update for one digit of every active lane.  Ordinary inputs have 64 different
-// buckets per wave and take the plain atomic; when neighbouring lanes hit the same bucket
-// (degenerate inputs: equal scalars, tiny windows) same-address atomics serialise (~12 ns each),
-// so such waves elect one lane per distinct bucket to add the whole multiplicity.
-// Returns this lane's rank within its bucket's reservation (old value + rank).
-__device__ __forceinline__ uint32_t bucket_atomic_add(uint32_t *counters, uint32_t g, bool active_lane) {
-    const unsigned long long act = __ballot(active_lane);
-    const int lane = threadIdx.x & 63;
-    const uint32_t gn = __shfl(g, (lane + 1) & 63, 64);
-    const unsigned long long dup = __ballot(active_lane && gn == g) & (act >> 1 | act << 63);
-    uint32_t res = 0;
-    if (__popcll(dup) < 8) {
-        if (active_lane) res = atomicAdd(&counters[g], 1u);
-        return res;
-    }
-    unsigned long long todo = act;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t gl = __shfl(g, leader, 64);
-        const unsigned long long same = __ballot(active_lane && g == gl) & todo;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&counters[gl], (uint32_t)__popcll(same));
-        base = __shfl(base, leader, 64);
-        if (active_lane && g == gl) res = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return res;
-}
-
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts,
-             uint8_t *__restrict__ valid, uint32_t *__restrict__ counts, unsigned long long *err) {
+             uint32_t *__restrict__ digits, unsigned long long *err) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool live = false;
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -136,17 +108,21 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
         int st = decode_point<F>(a, w);
         if (st != E_SUCCESS) {
             atomicMin(err, ((unsigned long long)i << 3) | (unsigned long long)st);
-            valid[i] = 0;
-        } else if (is_inf(a)) {
-            valid[i] = 0;
-        } else {
+        } else if (!is_inf(a)) {
             pts[i] = a;
-            valid[i] = 1;
             live = true;
             decode_scalar(k, w + Wire<F>::kPointWords);
         }
     }
-    for_each_digit(k, pl, [&](uint32_t g, uint32_t, bool nz) { bucket_atomic_add(counts, g, live && nz); });
+    if (i >= pl.n) return;
+    // digit array, window-major so that one window's digits of consecutive records are contiguous:
+    // 0 = no entry, else (bucket value << 1) | negate
+    int wi = 0;
+    for_each_digit(k, pl, [&](uint32_t g, uint32_t ng, bool nz) {
+        const uint32_t v = g - (uint32_t)wi * pl.B + 1u;                // bucket value 1..nb_w
+        digits[(size_t)wi * pl.n + i] = (live && nz) ? ((v << 1) | ng) : 0u;
+        wi++;
+    });
 }
 
 // Three-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
@@ -205,19 +181,78 @@ k_msm_scan_apply(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshi
     }
 }
 
-template <class F>
+// ---- counting sort of the (window, bucket) digits without global atomics -------------------------
+// Scattered global atomics run at ~25 G/s on this part (two passes of 16.8 M cost 1.35 ms at
+// 2^20).  Instead the records are cut into slices of kSlice; one block owns one (slice, window),
+// keeps that window's whole histogram in LDS as packed 16-bit counters (65536 x 2 B = 128 KB,
+// a slice cannot overflow them) and counts / ranks with LDS atomics only:
+//   k_msm_hist       [slice x window]  LDS histogram -> hist16[window][slice][bucket]
+//   k_msm_slicescan  [bucket]          exclusive scan over the slices -> base[window][slice][bucket]
+//                                      and the bucket totals counts[g]
+//   k_msm_scatter    [slice x window]  rank inside (slice, bucket) by LDS atomic; position =
+//                                      offsets[g] + base + rank
+static constexpr uint32_t kSlice = 32768;
+static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit counters
+
+__global__ void __launch_bounds__(1024)
+k_msm_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
+           uint32_t *__restrict__ hist16) {
+    __shared__ uint32_t h[kLdsWords];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
+    const uint32_t words = (nbw + 1u) / 2u;
+    for (uint32_t t = threadIdx.x; t < words; t += 1024u) h[t] = 0;
+    __syncthreads();
+    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+        const uint32_t v = digits[(size_t)w * pl.n + i];
+        if (v) { const uint32_t b = (v >> 1) - 1u; atomicAdd(&h[b >> 1], 1u << (16u * (b & 1u))); }
+    }
+    __syncthreads();
+    uint32_t *dst = hist16 + ((size_t)w * nslices + slice) * (nbmax / 2u);
+    for (uint32_t t = threadIdx.x; t < words; t += 1024u) dst[t] = h[t];
+}
+
 __global__ void __launch_bounds__(256)
-k_msm_scatter(const uint32_t *__restrict__ in, MsmPlan pl, const uint8_t *__restrict__ valid,
-              const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
-              uint32_t *__restrict__ entries) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool live = i < pl.n && valid[i];
-    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) decode_scalar(k, in + (size_t)i * Wire<F>::kMsmRecWords + Wire<F>::kPointWords);
-    for_each_digit(k, pl, [&](uint32_t g, uint32_t ng, bool nz) {
-        const uint32_t rank = bucket_atomic_add(cursor, g, live && nz);
-        if (live && nz) entries[offsets[g] + rank] = (i << 1) | ng;
-    });
+k_msm_slicescan(const uint32_t *__restrict__ hist16, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
+                uint32_t *__restrict__ base, uint32_t *__restrict__ counts) {
+    // one thread per packed pair of buckets of one window
+    const uint32_t w = blockIdx.y, pair = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
+    if (2u * pair >= nbw) return;
+    uint32_t run0 = 0, run1 = 0;
+    for (uint32_t sl = 0; sl < nslices; sl++) {
+        const size_t row = (size_t)w * nslices + sl;
+        const uint32_t v = hist16[row * (nbmax / 2u) + pair];
+        base[row * nbmax + 2u * pair] = run0;
+        base[row * nbmax + 2u * pair + 1u] = run1;
+        run0 += v & 0xffffu;
+        run1 += v >> 16;
+    }
+    counts[(size_t)w * pl.B + 2u * pair] = run0;
+    if (2u * pair + 1u < nbw) counts[(size_t)w * pl.B + 2u * pair + 1u] = run1;
+}
+
+__global__ void __launch_bounds__(1024)
+k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
+              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries) {
+    __shared__ uint32_t h[kLdsWords];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
+    const uint32_t words = (nbw + 1u) / 2u;
+    for (uint32_t t = threadIdx.x; t < words; t += 1024u) h[t] = 0;
+    __syncthreads();
+    const uint32_t *brow = base + ((size_t)w * nslices + slice) * nbmax;
+    const uint32_t *orow = offsets + (size_t)w * pl.B;
+    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+        const uint32_t v = digits[(size_t)w * pl.n + i];
+        if (v) {
+            const uint32_t b = (v >> 1) - 1u, sh = 16u * (b & 1u);
+            const uint32_t rank = (atomicAdd(&h[b >> 1], 1u << sh) >> sh) & 0xffffu;
+            entries[orow[b] + brow[b] + rank] = (i << 1) | (v & 1u);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -632,10 +667,13 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     const size_t nwin_out = (size_t)pl.W * red_blocks;
 
     HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
-    HIPCHK(e->valid.reserve(n));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
-    HIPCHK(e->cursor.reserve((size_t)pl.NB * 4));
+    const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
+    const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
+    HIPCHK(e->valid.reserve((size_t)pl.W * n * 4));                               // digits [W][n]
+    HIPCHK(e->cursor.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
+    HIPCHK(e->input2.reserve((size_t)pl.W * nslices * nbmax * 4));                // base   [W][slices][nbmax]
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
@@ -652,16 +690,15 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
     HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
     HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] lightly split [3] heavily split
-    HIPCHK(hipMemsetAsync(e->counts.p, 0, (size_t)pl.NB * 4, s));
-    HIPCHK(hipMemsetAsync(e->cursor.p, 0, (size_t)pl.NB * 4, s));
 
     const uint32_t rec_blocks = (uint32_t)((n + 255) / 256);
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
-    auto *valid = reinterpret_cast<uint8_t *>(e->valid.p);
+    auto *digits = reinterpret_cast<uint32_t *>(e->valid.p);
     auto *counts = reinterpret_cast<uint32_t *>(e->counts.p);
     auto *offsets = reinterpret_cast<uint32_t *>(e->offsets.p);
-    auto *cursor = reinterpret_cast<uint32_t *>(e->cursor.p);
+    auto *hist16 = reinterpret_cast<uint32_t *>(e->cursor.p);
+    auto *base = reinterpret_cast<uint32_t *>(e->input2.p);
     auto *taskoff = reinterpret_cast<uint32_t *>(e->taskoff.p);
     auto *entries = reinterpret_cast<uint32_t *>(e->entries.p);
     auto *tasks = reinterpret_cast<Task *>(e->tasks.p);
@@ -669,7 +706,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
 
     HIPCHK(hipEventRecord(e->ev_start, s));
-    hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, valid, counts, err);
+    hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, digits, err);
+    hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);
+    hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
     auto *blk = reinterpret_cast<uint32_t *>(e->scalars.p);
     uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
@@ -679,7 +718,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    hipLaunchKernelGGL(k_msm_scatter<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, valid, offsets, cursor, entries);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
