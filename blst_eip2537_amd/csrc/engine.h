@@ -19,18 +19,25 @@ struct Engine {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr;
-    // staging + workspace
-    DevBuf input, input2, pts, valid, counts, offsets, cursor, taskoff, entries, tasks, partial, winout, scalars, misc, perm, heavy;
-    void *host_pinned = nullptr;
-    size_t host_pinned_cap = 0;
+    // staging + per-call workspace (grow-only)
+    DevBuf input;          // H2D copy of a host caller's records
+    DevBuf misc;           // first-error word, scan totals, split-bucket counters
+    // MSM
+    DevBuf pts;            // decoded affine points, AoS
+    DevBuf digits;         // [window][record] bucket value / sign
+    DevBuf hist16;         // [window][slice][bucket] packed 16-bit slice histograms
+    DevBuf slice_base;     // [window][slice][bucket] exclusive prefix over the slices
+    DevBuf counts, offsets, taskoff;   // per bucket: entries, first entry, first task
+    DevBuf scan_blk;       // block totals of the bucket scan + task-length histogram
+    DevBuf entries;        // (record << 1 | sign), sorted by bucket
+    DevBuf tasks, perm;    // <= L-entry runs of one bucket; tasks ordered by length
+    DevBuf split_lists;    // buckets split into several tasks: lightly | heavily
+    DevBuf partial;        // one XYZZ point per task        (pairing: the 68 x k line records)
+    DevBuf winout;         // per (window, reduce block) sums (pairing: per-block / per-step Fp12 products)
     // last-call kernel timing (ms), filled when timing is enabled
     float last_kernel_ms = 0.f;   // whole device pipeline of the last call
     float last_accum_ms = 0.f;    // dominant kernel of the last call (k_msm_accum / k_pair_miller)
 };
-
-// Acquire the process-wide engine (lazy init).  Returns nullptr and logs loudly on failure.
-Engine *engine_acquire();
-void engine_release();
 
 // Window plan for one MSM
 struct MsmPlan {

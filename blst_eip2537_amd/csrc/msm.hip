@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <vector>
 #include "codec.h"
+#include "lanes.h"
 #include "engine.h"
 
 namespace eip {
@@ -315,44 +316,12 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
     if (len) perm[base[len] + local] = t;
 }
 
-// ---- wavefront shuffles / selects of field elements (lane-group kernels)
-__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
-    return r;
-}
-__device__ __forceinline__ FpI shfl_from(const FpI &a, int src) { return FpI{shfl_from(a.v, src)}; }
-__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
-template <class T> __device__ __forceinline__ Xyzz<T> shfl_from(const Xyzz<T> &p, int src) {
-    return Xyzz<T>{shfl_from(p.x, src), shfl_from(p.y, src), shfl_from(p.zz, src), shfl_from(p.zzz, src)};
-}
-__device__ __forceinline__ Fp sel4(int r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
-    Fp o;
-#pragma unroll
-    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
-    return o;
-}
-__device__ __forceinline__ FpI sel4(int r, const FpI &a, const FpI &b, const FpI &c, const FpI &d) { return FpI{sel4(r, a.v, b.v, c.v, d.v)}; }
-__device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
-    return Fp2{sel4(r, a.c0, b.c0, c.c0, d.c0), sel4(r, a.c1, b.c1, c.c1, d.c1)};
-}
-
 // ---- G2 accumulate, 2 lanes per task ----------------------------------------------------------
 // Over Fp2 a one-lane mixed addition keeps ~15 Fp2 values live (256 VGPR + 191 AGPR + scratch,
 // one wave per SIMD) and ran at a fifth of the G1 kernel's product rate.  Here a task owns two
 // lanes: the ten products of madd-2008-s are dealt two per round in five rounds
 //   [U2 S2] [PP RR] [PPP Q] [ZZ3 Y1*PPP] [R*(Q-X3) ZZZ3]
 // (every lane busy in every round), halving the chain and doubling the waves.
-__device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
-    Fp2 o;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        o.c0.l[i] = r == 0 ? a.c0.l[i] : b.c0.l[i];
-        o.c1.l[i] = r == 0 ? a.c1.l[i] : b.c1.l[i];
-    }
-    return o;
-}
 __device__ __forceinline__ Xyzz<Fp2> madd2(const Xyzz<Fp2> &p, const Aff<Fp2> &q, int r, int gb) {
     if (is_inf(q)) return p;                                   // uniform in the pair of lanes
     if (is_inf(p)) return Xyzz<Fp2>{q.x, q.y, fp2_one(), fp2_one()};
@@ -419,18 +388,6 @@ k_msm_accum(const Aff<F> *__restrict__ pts_, const uint32_t *__restrict__ entrie
     partial[t] = acc;
 }
 
-// ---- wavefront shuffles of field elements and points (64 lanes)
-__device__ __forceinline__ Fp shfl_down(const Fp &a, int off) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = __shfl_down(a.l[i], off, 64);
-    return r;
-}
-__device__ __forceinline__ Fp2 shfl_down(const Fp2 &a, int off) { return Fp2{shfl_down(a.c0, off), shfl_down(a.c1, off)}; }
-template <class F> __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F> &p, int off) {
-    return Xyzz<F>{shfl_down(p.x, off), shfl_down(p.y, off), shfl_down(p.zz, off), shfl_down(p.zzz, off)};
-}
-
 // ---- fold: buckets that were split into several tasks ------------------------------------------
 // A bucket with more than L entries (the top window when it has only a few bits, duplicate-heavy
 // or adversarial inputs: all scalars equal puts every record of a window into ONE bucket) leaves
@@ -438,7 +395,9 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F> &p
 // reduce kernels read.  (Summing them serially inside the reduce cost 93 ms at n = 2^18, where the
 // top window has 1 bit and its two buckets ~2000 tasks each; a block per split bucket cost 30 ms
 // when most buckets had 2-4 tasks -- hence two tiers, and L grows with the mean bucket load.)
-template <class T> static __device__ __noinline__ void xyzz_add_f(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
+// out-of-line complete point operations (fold and one-lane reduce kernels)
+template <class T> static __device__ __noinline__ void xyzz_add_o(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
+template <class T> static __device__ __noinline__ void xyzz_dbl_o(Xyzz<T> *r, const Xyzz<T> *a) { *r = dbl(*a); }
 // 2..8 tasks: one thread per bucket
 template <class F>
 __global__ void __launch_bounds__(256)
@@ -450,7 +409,7 @@ k_msm_fold_small(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ tas
         Xyzz<F> acc = partial[t0];
         for (uint32_t t = t0 + 1; t < t1; t++) {
             Xyzz<F> pt = partial[t];
-            xyzz_add_f<F>(&acc, &acc, &pt);
+            xyzz_add_o<F>(&acc, &acc, &pt);
         }
         partial[t0] = acc;
     }
@@ -468,16 +427,16 @@ k_msm_fold_big(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ tasko
         Xyzz<F> acc = xyzz_inf<F>();
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
             Xyzz<F> pt = partial[t];
-            xyzz_add_f<F>(&acc, &acc, &pt);
+            xyzz_add_o<F>(&acc, &acc, &pt);
         }
         for (int off = 32; off >= 1; off >>= 1) {
             Xyzz<F> o = shfl_down(acc, off);
-            if (lane < off) xyzz_add_f<F>(&acc, &acc, &o);
+            if (lane < off) xyzz_add_o<F>(&acc, &acc, &o);
         }
         if (lane == 0) sm[wave] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 1; k < 4; k++) xyzz_add_f<F>(&acc, &acc, &sm[k]);
+            for (int k = 1; k < 4; k++) xyzz_add_o<F>(&acc, &acc, &sm[k]);
             partial[t0] = acc;
         }
         __syncthreads();
@@ -577,9 +536,6 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
 // Measured at 2^20 / c = 16: 1.55 ms against 1.8-2.1 ms for the 4-lane form above (whose per-round
 // select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
 // products are 3x heavier and the 4-lane form wins 2.2 ms to 7.0 ms at 2^16.
-template <class T> static __device__ __noinline__ void xyzz_add_o(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
-template <class T> static __device__ __noinline__ void xyzz_dbl_o(Xyzz<T> *r, const Xyzz<T> *a) { *r = dbl(*a); }
-
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl,
@@ -671,18 +627,18 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
     const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
-    HIPCHK(e->valid.reserve((size_t)pl.W * n * 4));                               // digits [W][n]
-    HIPCHK(e->cursor.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
-    HIPCHK(e->input2.reserve((size_t)pl.W * nslices * nbmax * 4));                // base   [W][slices][nbmax]
+    HIPCHK(e->digits.reserve((size_t)pl.W * n * 4));                               // digits [W][n]
+    HIPCHK(e->hist16.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
+    HIPCHK(e->slice_base.reserve((size_t)pl.W * nslices * nbmax * 4));                // base   [W][slices][nbmax]
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
     HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scalars.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
+    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
-    HIPCHK(e->heavy.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
+    HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
     hipStream_t s = e->stream;
@@ -694,11 +650,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     const uint32_t rec_blocks = (uint32_t)((n + 255) / 256);
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
-    auto *digits = reinterpret_cast<uint32_t *>(e->valid.p);
+    auto *digits = reinterpret_cast<uint32_t *>(e->digits.p);
     auto *counts = reinterpret_cast<uint32_t *>(e->counts.p);
     auto *offsets = reinterpret_cast<uint32_t *>(e->offsets.p);
-    auto *hist16 = reinterpret_cast<uint32_t *>(e->cursor.p);
-    auto *base = reinterpret_cast<uint32_t *>(e->input2.p);
+    auto *hist16 = reinterpret_cast<uint32_t *>(e->hist16.p);
+    auto *base = reinterpret_cast<uint32_t *>(e->slice_base.p);
     auto *taskoff = reinterpret_cast<uint32_t *>(e->taskoff.p);
     auto *entries = reinterpret_cast<uint32_t *>(e->entries.p);
     auto *tasks = reinterpret_cast<Task *>(e->tasks.p);
@@ -710,10 +666,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
-    auto *blk = reinterpret_cast<uint32_t *>(e->scalars.p);
+    auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
     uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
-    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->heavy.p), *split_big = split_small + pl.NB;
+    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);

@@ -27,6 +27,7 @@
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
+#include "lanes.h"
 #include "engine.h"
 
 namespace eip {
@@ -62,22 +63,6 @@ k_pair_check_g1(const uint32_t *__restrict__ in, uint32_t k, unsigned long long 
 // lane keeps the whole running point T, and the independent Fp2 products of a doubling step are
 // dealt one per lane in three rounds ([X^2 Y^2 Z^2 YZ], [B^2 (X+B)^2 E^2 EX], [E ZZ, Z3 ZZ,
 // E(D-X3)]), the results exchanged with shuffles; the cheap linear steps are replicated.
-__device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
-    return r;
-}
-__device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shfl_from(a.c0, src), shfl_from(a.c1, src)}; }
-__device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
-    Fp2 o;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        o.c0.l[i] = r == 0 ? a.c0.l[i] : r == 1 ? b.c0.l[i] : r == 2 ? c.c0.l[i] : d.c0.l[i];
-        o.c1.l[i] = r == 0 ? a.c1.l[i] : r == 1 ? b.c1.l[i] : r == 2 ? c.c1.l[i] : d.c1.l[i];
-    }
-    return o;
-}
 // same result as miller_dbl_step (pairing.h), products dealt over the 4 lanes of the group
 __device__ __forceinline__ Line miller_dbl_step4(MillerT &T, int r, int gbase) {
     Fp2 pr = fp2_mul_body(sel4(r, T.x, T.y, T.z, T.y), sel4(r, T.x, T.y, T.z, T.z));   // inlined: hot loop
