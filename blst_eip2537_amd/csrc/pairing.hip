@@ -15,7 +15,7 @@
 //                           68 sparse lines (a0, a1 xP, a4 yP); the walk ends at T = [|z|]Q,
 //                           which IS the G2 membership test psi(Q) == -[|z|]Q
 //   k_pair_check_g1 [pair]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
-//   k_pair_tree    [16 lines of one step per 8-lane group]  each Fp12 is spread over a lane
+//   k_pair_tree    [a run of lines of one step per 8-lane group]  each Fp12 is spread over a lane
 //                           group (one Fp2 coefficient per lane); sparse line products, then a
 //                           per-wave product tree over shuffles and an LDS step across waves
 //   k_pair_tree2   [step]   the few per-block products of a step -> L_s (same lane-group form)
@@ -23,6 +23,7 @@
 //                           exponentiation, == 1     (once per call, like the reference)
 // Errors are merged with atomicMin on (pair << 4 | stage << 3 | code): lowest pair first, and
 // inside a pair the reference's order G1 decode -> G1 subgroup -> G2 decode -> G2 subgroup.
+#include <algorithm>
 #include <stdio.h>
 #include <vector>
 #include "codec.h"
@@ -192,19 +193,18 @@ __device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, 
     }
 }
 
-static constexpr int kGroupLines = 16;      // lines folded serially by one group before the tree
 
-// grid (blocks, 68 steps), 256 threads = 32 groups: each group folds kGroupLines lines of its
+// grid (blocks, 68 steps), 256 threads = 32 groups: each group folds `group_lines` lines of its
 // step into a dense element, then wave tree (shuffles) and an LDS step across the 4 waves.
 __global__ void __launch_bounds__(256)
-k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk_out) {
+k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk_out, uint32_t group_lines) {
     __shared__ Fp2 sm[4][6];
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, gbase = lane & ~7;
     const uint32_t g = blockIdx.x * 32u + (threadIdx.x >> 3);
     Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
-    for (int j = 0; j < kGroupLines; j++) {
-        const uint32_t i = g * kGroupLines + j;
+    for (uint32_t j = 0; j < group_lines; j++) {
+        const uint32_t i = g * group_lines + j;
         if (i < k) {
             LineRec l = lines[(size_t)s * k + i];
             acc = grp_mul_line(acc, l, sub, gbase);
@@ -244,7 +244,12 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     }
     const uint32_t blocks = (uint32_t)((k + 63) / 64);
     const uint32_t line_blocks = (uint32_t)((k + 15) / 16);       // 4 lanes per pair
-    const uint32_t tree_blocks = (uint32_t)((k + 32 * kGroupLines - 1) / (32 * kGroupLines));
+    // lines folded serially per 8-lane group: as few as possible while the whole grid (blocks x 68
+    // steps) still fits in ONE round of 2 blocks per CU (512 slots); one block more than that and
+    // the kernel takes two block-times (measured: 544 blocks 1.8 ms)
+    const uint32_t max_blocks_per_step = 512u / kSteps;                         // 7
+    const uint32_t group_lines = (uint32_t)std::max<size_t>(1, (k + 32 * max_blocks_per_step - 1) / (32 * max_blocks_per_step));
+    const uint32_t tree_blocks = (uint32_t)((k + 32 * group_lines - 1) / (32 * group_lines));
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->partial.reserve((size_t)kSteps * k * sizeof(LineRec)));
     HIPCHK(e->winout.reserve(((size_t)kSteps * tree_blocks + kSteps) * sizeof(Fp12)));
@@ -264,7 +269,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     HIPCHK(hipEventRecord(e->ev_a, s));
     hipLaunchKernelGGL(k_pair_lines, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, (uint32_t)k, blk_out);
+    hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, (uint32_t)k, blk_out, group_lines);
     hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));
