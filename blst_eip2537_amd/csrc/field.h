@@ -97,19 +97,16 @@ HD Fp fp_reduce_once(const Fp &t) {
 #if !defined(__HIP_DEVICE_COMPILE__)
     return hostfp::store(hostfp::reduce_once(hostfp::load(t)));
 #else
+    // device: native carry chains (v_subb_co_u32); the 64-bit-arithmetic spelling of the same loop
+    // compiled to v_lshl_add_u64 + zero-extension moves, ~3x the instructions
     const Fp p = fp_p();
     Fp d;
-    uint32_t borrow = 0;
+    unsigned borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t s = (uint64_t)t.l[i] - p.l[i] - borrow;
-        d.l[i] = (uint32_t)s;
-        borrow = (uint32_t)(s >> 32) & 1u;
-    }
-    uint32_t keep_t = 0u - borrow;   // all ones when t < p
+    for (int i = 0; i < 12; i++) d.l[i] = __builtin_subc(t.l[i], p.l[i], borrow, &borrow);
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = (t.l[i] & keep_t) | (d.l[i] & ~keep_t);
+    for (int i = 0; i < 12; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
     return r;
 #endif
 }
@@ -118,13 +115,9 @@ HD Fp add(const Fp &a, const Fp &b) {
     return hostfp::store(hostfp::add(hostfp::load(a), hostfp::load(b)));
 #else
     Fp t;
-    uint32_t c = 0;
+    unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t s = (uint64_t)a.l[i] + b.l[i] + c;
-        t.l[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
+    for (int i = 0; i < 12; i++) t.l[i] = __builtin_addc(a.l[i], b.l[i], c, &c);
     return fp_reduce_once(t);     // a + b < 2p < 2^384: no carry out
 #endif
 }
@@ -133,22 +126,15 @@ HD Fp sub(const Fp &a, const Fp &b) {
     return hostfp::store(hostfp::sub(hostfp::load(a), hostfp::load(b)));
 #else
     const Fp p = fp_p();
-    Fp d;
-    uint32_t borrow = 0;
+    Fp d, e;
+    unsigned borrow = 0, c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t s = (uint64_t)a.l[i] - b.l[i] - borrow;
-        d.l[i] = (uint32_t)s;
-        borrow = (uint32_t)(s >> 32) & 1u;
-    }
-    uint32_t mask = 0u - borrow, c = 0;
+    for (int i = 0; i < 12; i++) d.l[i] = __builtin_subc(a.l[i], b.l[i], borrow, &borrow);
+#pragma unroll
+    for (int i = 0; i < 12; i++) e.l[i] = __builtin_addc(d.l[i], p.l[i], c, &c);
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t s = (uint64_t)d.l[i] + (p.l[i] & mask) + c;
-        r.l[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
+    for (int i = 0; i < 12; i++) r.l[i] = borrow ? e.l[i] : d.l[i];
     return r;
 #endif
 }
