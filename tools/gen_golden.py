@@ -111,7 +111,9 @@ if __name__ == "__main__":
     print("kat.json written")
     if "--kat-only" in sys.argv:
         sys.exit(0)
-    for wl, l2 in [("g1msm", 10), ("g1msm", 16), ("g1msm", 20), ("g2msm", 10), ("g2msm", 16)]:
+    # 2^21..2^23: the totals of bench.py's weak-scaling runs on 2 / 4 / 8 GPUs
+    for wl, l2 in [("g1msm", 10), ("g1msm", 16), ("g1msm", 20), ("g1msm", 21), ("g1msm", 22), ("g1msm", 23),
+                   ("g2msm", 10), ("g2msm", 16)]:
         with open(os.path.join(OUT, "%s_2p%d.hex" % (wl, l2)), "w") as f:
             f.write(analytic(wl, l2).hex() + "\n")
         print(wl, l2, "written")
