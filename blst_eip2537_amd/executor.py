@@ -96,11 +96,13 @@ def lib():
 
 
 def _call(name, inp):
-    inp = bytes(inp)
+    if not isinstance(inp, bytes):
+        inp = bytes(inp)
     out = ctypes.create_string_buffer(_ABI[name])
-    # zero-length input: pass a non-null dangling pointer like Rust does (rust/src/lib.rs:147);
-    # the library must not dereference it.
-    buf = ctypes.create_string_buffer(inp, len(inp)) if inp else ctypes.create_string_buffer(1)
+    # the bytes object is passed as is (no copy: the library never writes `in`); a zero-length
+    # input becomes a non-null dangling pointer like Rust's (rust/src/lib.rs:147), which the
+    # library must not dereference.
+    buf = ctypes.cast(ctypes.c_char_p(inp), ctypes.c_void_p) if inp else ctypes.create_string_buffer(1)
     rc = getattr(lib(), name)(out, buf, len(inp))
     if rc != 0:
         raise Eip2537Error(rc)
