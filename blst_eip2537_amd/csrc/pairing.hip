@@ -10,8 +10,9 @@
 //        F = prod_i f_i,   f_i = (...((l_{i,0})^2 l_{i,1})^2 ...)        =>
 //        F = (...((L_0)^2 L_1)^2 ...),   L_s = prod_i l_{i,s}
 // because squaring distributes over the product.  So:
-//   k_pair_lines   [pair, 4 lanes each]  walk T = Q, 2Q, ... on the twist (Fp2 only), the
-//                           independent products of a step dealt over the 4 lanes; store the
+//   k_pair_lines4/16 [pair, 4 or 16 lanes each]  walk T = Q, 2Q, ... on the twist (Fp2 only),
+//                           the independent products of a step dealt over the lanes (one Fp2
+//                           product per lane, or one Fp product per lane for batches <= 2048); store the
 //                           68 sparse lines (a0, a1 xP, a4 yP); the walk ends at T = [|z|]Q,
 //                           which IS the G2 membership test psi(Q) == -[|z|]Q
 //   k_pair_check_g1 [pair]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
@@ -102,7 +103,7 @@ __device__ __forceinline__ void store_line4(LineRec *dst, const Line &l, const A
 }
 
 __global__ void __launch_bounds__(64)
-k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+k_pair_lines4(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
     // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
     // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
     __shared__ Aff<Fp> sP[16];
@@ -152,6 +153,114 @@ k_pair_lines(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ 
     Fp2 zz = sqr(T.z);
     bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
     if (!in_sub && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+}
+
+// ---- line walk, 16 lanes per pair -------------------------------------------------------------
+// A lone wave issues one VALU instruction every ~4-8 cycles, so one pair per lane made the
+// 63-step walk a 2400-product serial chain on 64 waves.  Here a pair owns a 16-lane group: every
+// lane keeps the whole running point T, and the independent Fp2 products of a doubling step
+//   round 1 [X^2  Y^2  Z^2  YZ]   round 2 [B^2  (X+B)^2  E^2  EX]   round 3 [E ZZ  Z3 ZZ  E(D-X3)]
+// are dealt over 12 lanes, ONE Fp product each: lane 3p+q computes Karatsuba part q of product p
+// (a0 b0, a1 b1, (a0+a1)(b0+b1)); the triple combines them and the four Fp2 results are
+// broadcast with shuffles.  The cheap linear steps are replicated on all lanes.
+struct Prod4 { Fp2 r0, r1, r2, r3; };
+__device__ __forceinline__ Prod4 fp2_products4(const Fp2 &u, const Fp2 &v, int q, int tb, int gbase) {
+    // this lane's Karatsuba part of its product (operands u, v already selected by product index)
+    const Fp x = q == 0 ? u.c0 : (q == 1 ? u.c1 : add(u.c0, u.c1));
+    const Fp y = q == 0 ? v.c0 : (q == 1 ? v.c1 : add(v.c0, v.c1));
+    const Fp t = fp_mul_cols28(x, y);
+    const Fp t0 = shfl_from(t, tb), t1 = shfl_from(t, tb + 1), t2 = shfl_from(t, tb + 2);
+    const Fp c = q == 0 ? sub(t0, t1) : sub(sub(t2, t0), t1);       // lane q=0: c0, lane q=1: c1
+    Prod4 o;
+    o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
+    o.r1 = Fp2{shfl_from(c, gbase + 3), shfl_from(c, gbase + 4)};
+    o.r2 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
+    o.r3 = Fp2{shfl_from(c, gbase + 9), shfl_from(c, gbase + 10)};
+    return o;
+}
+// same result as miller_dbl_step (pairing.h)
+__device__ __forceinline__ Line miller_dbl_step16(MillerT &T, int p, int q, int tb, int gbase) {
+    Prod4 pr = fp2_products4(sel4(p, T.x, T.y, T.z, T.y), sel4(p, T.x, T.y, T.z, T.z), q, tb, gbase);
+    const Fp2 A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
+    const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
+    pr = fp2_products4(sel4(p, B, XB, E, E), sel4(p, B, XB, E, T.x), q, tb, gbase);
+    const Fp2 C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
+    const Fp2 D = dbl(sub(sub(t, A), C));
+    const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
+    pr = fp2_products4(sel4(p, E, Z3, E, E), sel4(p, ZZ, ZZ, sub(D, X3), ZZ), q, tb, gbase);
+    const Fp2 EZ = pr.r0, Z3ZZ = pr.r1, Ym = pr.r2;
+    Line l;
+    l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
+    l.a1 = neg(EZ);                   // -3X^2 Z^2
+    l.a4 = Z3ZZ;                      // 2YZ^3
+    T.x = X3;
+    T.y = sub(Ym, dbl(dbl(dbl(C))));
+    T.z = Z3;
+    return l;
+}
+// scale (a1, a4) by (xP, yP): four Fp products on lanes 0..3; then lanes 0..2 store a0, a1, a4
+__device__ __forceinline__ void store_line16(LineRec *dst, const Line &l, const Aff<Fp> *P, bool contributes, int sub_lane, int gbase) {
+    const int r = sub_lane & 3;
+    Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
+    Fp qv = fp_mul_cols28(w, r < 2 ? P->x : P->y);
+    Fp2 a1{shfl_from(qv, gbase), shfl_from(qv, gbase + 1)}, a4{shfl_from(qv, gbase + 2), shfl_from(qv, gbase + 3)};
+    Fp2 v = sub_lane == 0 ? l.a0 : (sub_lane == 1 ? a1 : a4);
+    if (!contributes) v = sub_lane == 0 ? fp2_one() : fp2_zero();
+    if (sub_lane < 3) (&dst->a0)[sub_lane] = v;
+}
+
+__global__ void __launch_bounds__(64)
+k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+    // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
+    // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
+    __shared__ Aff<Fp> sP[4];
+    __shared__ Aff<Fp2> sQ[4];
+    const int lane = threadIdx.x & 63, sl = lane & 15, gbase = lane & ~15, gi = lane >> 4;
+    const int pidx = sl / 3 < 3 ? sl / 3 : 3, q = sl - 3 * (sl / 3), tb = gbase + 3 * pidx;   // lanes 12..15 shadow product 3
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 4);
+    bool q_live = false, contributes = false;
+    MillerT T;
+    if (i < k) {                              // uniform within a 16-lane group
+        Aff<Fp> P;
+        Aff<Fp2> Q;
+        int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
+        int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
+        if (s2 != E_SUCCESS && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
+        q_live = s2 == E_SUCCESS && !is_inf(Q);
+        contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
+        if (sl == 0) { sP[gi] = P; sQ[gi] = Q; }
+        T = MillerT{Q.x, Q.y, fp2_one()};
+    }
+    __syncthreads();
+    if (i >= k) return;
+    if (!q_live) {
+        if (sl < 3) {
+            Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
+            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[sl] = v;
+        }
+        return;
+    }
+    const uint64_t z = K_Z_ABS;
+    int s = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        Line l = miller_dbl_step16(T, pidx, q, tb, gbase);
+        store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+        s++;
+        if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
+            Aff<Fp2> Q = sQ[gi];
+            l = miller_add_step(T, Q);
+            store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+            s++;
+        }
+    }
+    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T
+    //   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
+    Aff<Fp2> Q = sQ[gi];
+    Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
+    Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
+    Fp2 zz = sqr(T.z);
+    bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
+    if (!in_sub && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
 // ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
@@ -250,7 +359,10 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
         return E_MEMORY_ERROR;
     }
     const uint32_t blocks = (uint32_t)((k + 63) / 64);
-    const uint32_t line_blocks = (uint32_t)((k + 15) / 16);       // 4 lanes per pair
+    // 16 lanes per pair shorten the serial chain (small batches: 16 pairs 3.1 -> 2.7 ms) but replicate
+    // the linear steps 4x more and put a wave on every SIMD at 2^12 pairs (3.4 vs 2.0 ms): by size
+    const bool wide = k <= 2048;
+    const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : (uint32_t)((k + 15) / 16);
     // lines folded serially per 8-lane group: as few as possible while the whole grid (blocks x 68
     // steps) still fits in ONE round of 2 blocks per CU (512 slots); one block more than that and
     // the kernel takes two block-times (measured: 544 blocks 1.8 ms)
@@ -274,7 +386,8 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipLaunchKernelGGL(k_pair_check_g1, dim3(blocks), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
-    hipLaunchKernelGGL(k_pair_lines, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
+    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
+    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
     hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, (uint32_t)k, blk_out, group_lines);
     hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);

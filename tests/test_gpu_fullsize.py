@@ -143,3 +143,16 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
     # G2 with a heavy top window
     inp = X.gen_msm_input("g2", 1 << 12, A, B, 1212)
     assert call_x(X.g2_multiexp, inp) == clib.call("bls12_g2multiexp", inp)
+
+
+def test_pairing_both_walk_kernels_ragged_sizes(X, clib):
+    """k <= 2048 runs the 16-lane line walk, larger batches the 4-lane one; ragged sizes around the
+    switch, each closed to the identity and broken by one, and an error in the last (partial) group."""
+    for k in (2047, 2049, 2100):
+        good, bad = _pairing_batch(X, k, 0), _pairing_batch(X, k, 1)
+        assert call_x(X.pairing, good) == (0, bytes(31) + b"\x01"), k
+        assert call_x(X.pairing, bad) == (0, bytes(32)), k
+        t = bytearray(good)
+        t[(k - 2) * 384 + 128:(k - 2) * 384 + 384] = m.encode_fp(1) * 4       # G2 off curve in pair k-2
+        assert call_x(X.pairing, bytes(t)) == (1, None), k
+    assert clib.call("bls12_pairing", _pairing_batch(X, 2100, 0)) == (0, bytes(31) + b"\x01")
