@@ -11,6 +11,8 @@
 // Single-pair operations (add, mul, map) are host code of this library (BASELINE config 1 is
 // "CPU plumbing, no GPU"); the multiexp and pairing paths have no CPU implementation here at all:
 // without a working HIP device they fail loudly with EIP2537_MEMORY_ERROR.
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,13 +43,30 @@ void DevBuf::release() {
     cap = 0;
 }
 
-static std::mutex g_mu;         // serialises GPU calls: the ABI has no handle to hang state on
-static Engine g_engine;
+// Engine slots.  The ABI has no handle to hang state on and its callers are concurrent (cargo's
+// test threads, goroutines: SURVEY.md 8b "Threading"), so the library keeps a small pool of
+// engines -- each with its own streams, events and grow-only workspace -- and a call borrows one
+// for its duration.  Calls on different slots overlap on the GPU (small inputs fill a fraction of
+// the 256 CUs); when every slot is busy a caller waits for the next release.
+static constexpr int kMaxSlots = 16;
+static std::mutex g_mu;                 // guards the slot table and one-time device selection
+static std::condition_variable g_cv;
+static Engine g_slots[kMaxSlots];
+static bool g_busy[kMaxSlots];
+static int g_nslots = 0;                // 0 = device not selected yet
+static int g_device = 0;
 static int g_device_request = -1;
-static int g_window_override = 0;
+static std::atomic<int> g_window_override{0};
+static thread_local float t_last_kernel_ms = 0.f, t_last_accum_ms = 0.f;
+static float g_last_kernel_ms = 0.f, g_last_accum_ms = 0.f;
 
-static bool engine_init_locked() {
-    if (g_engine.ready) return true;
+static bool device_select_locked() {
+    if (g_nslots) return true;
+    // Each slot drives up to three streams; the HIP runtime multiplexes a process's streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise) and streams sharing a queue run
+    // one after the other.  Ask for more before the runtime starts, unless the embedder chose a
+    // value (no effect, and no harm, when HIP was already initialised by the host program).
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     hipError_t er = hipGetDeviceCount(&ndev);
     if (er != hipSuccess || ndev == 0) {
@@ -62,17 +81,60 @@ static bool engine_init_locked() {
     }
     if (dev >= ndev) dev = dev % ndev;
     if (hipSetDevice(dev) != hipSuccess) { fprintf(stderr, "[eip2537_hip] FATAL: hipSetDevice(%d) failed\n", dev); return false; }
-    g_engine.device = dev;
-    bool ok = hipStreamCreateWithFlags(&g_engine.stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&g_engine.stream2, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&g_engine.stream3, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreate(&g_engine.ev_start) == hipSuccess && hipEventCreate(&g_engine.ev_stop) == hipSuccess &&
-              hipEventCreate(&g_engine.ev_a) == hipSuccess && hipEventCreate(&g_engine.ev_b) == hipSuccess &&
-              hipEventCreate(&g_engine.ev_j2) == hipSuccess && hipEventCreate(&g_engine.ev_j3) == hipSuccess;
-    if (!ok) { fprintf(stderr, "[eip2537_hip] FATAL: stream/event creation failed\n"); return false; }
-    g_engine.ready = true;
+    g_device = dev;
+    const char *env = getenv("EIP2537_HIP_SLOTS");
+    int ns = env ? atoi(env) : 8;
+    g_nslots = ns < 1 ? 1 : ns > kMaxSlots ? kMaxSlots : ns;
     return true;
 }
+static bool slot_init(Engine &e) {
+    if (e.ready) return true;
+    e.device = g_device;
+    bool ok = hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&e.stream3, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&e.ev_start) == hipSuccess && hipEventCreate(&e.ev_stop) == hipSuccess &&
+              hipEventCreate(&e.ev_a) == hipSuccess && hipEventCreate(&e.ev_b) == hipSuccess &&
+              hipEventCreate(&e.ev_j2) == hipSuccess && hipEventCreate(&e.ev_j3) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[eip2537_hip] FATAL: stream/event creation failed\n"); return false; }
+    e.ready = true;
+    return true;
+}
+// Borrow an engine for one call (RAII).  `e` is null when no device is usable.
+struct SlotLease {
+    Engine *e = nullptr;
+    int idx = -1;
+    SlotLease() {
+        std::unique_lock<std::mutex> lk(g_mu);
+        if (!device_select_locked()) return;
+        for (;;) {
+            for (int i = 0; i < g_nslots; i++)
+                if (!g_busy[i]) { idx = i; break; }
+            if (idx >= 0) break;
+            g_cv.wait(lk);
+        }
+        g_busy[idx] = true;
+        lk.unlock();
+        // the slot is ours now: create its streams outside the table lock
+        if (hipSetDevice(g_device) == hipSuccess && slot_init(g_slots[idx])) { e = &g_slots[idx]; return; }
+        lk.lock();
+        g_busy[idx] = false;
+        idx = -1;
+        g_cv.notify_one();
+    }
+    ~SlotLease() {
+        if (idx < 0) return;
+        t_last_kernel_ms = e->last_kernel_ms;
+        t_last_accum_ms = e->last_accum_ms;
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_last_kernel_ms = t_last_kernel_ms;
+        g_last_accum_ms = t_last_accum_ms;
+        g_busy[idx] = false;
+        g_cv.notify_one();
+    }
+    SlotLease(const SlotLease &) = delete;
+    SlotLease &operator=(const SlotLease &) = delete;
+};
 
 // Host -> device staging of the caller's buffer.  The copy is complete before this returns, so
 // the caller's pointer is never retained (Go / Rust own the memory: SURVEY.md 8b "Ownership").
@@ -125,16 +187,15 @@ template <class F> static int host_mul(byte *out, const byte *in, size_t in_len)
 }
 
 template <class F> static int msm_dispatch(Engine *e, const void *d_in, size_t n, uint32_t *pw);
-template <> int msm_dispatch<Fp>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g1_device(e, d_in, n, pw, g_window_override); }
-template <> int msm_dispatch<Fp2>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g2_device(e, d_in, n, pw, g_window_override); }
+template <> int msm_dispatch<Fp>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g1_device(e, d_in, n, pw, g_window_override.load()); }
+template <> int msm_dispatch<Fp2>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g2_device(e, d_in, n, pw, g_window_override.load()); }
 
 // mode: 0 = host input (stage it), 1 = device input; want_partial: write the XYZZ partial
 template <class F>
 static int msm_entry(byte *out, const void *in, size_t n, bool device_input, bool want_partial) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!engine_init_locked()) return E_MEMORY_ERROR;
-    Engine *e = &g_engine;
-    if (hipSetDevice(e->device) != hipSuccess) return E_MEMORY_ERROR;
+    SlotLease lease;
+    Engine *e = lease.e;
+    if (!e) return E_MEMORY_ERROR;
     const void *d_in = in;
     if (!device_input) {
         int st = stage_input(e, in, n * Wire<F>::kMsmRecWords * 4);
@@ -173,10 +234,9 @@ static void pairing_finish(byte *out, const Fp12 &ml) {
     if (one) out[31] = 1;
 }
 static int pairing_entry(byte *out, const void *in, size_t k, bool device_input, bool want_partial) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!engine_init_locked()) return E_MEMORY_ERROR;
-    Engine *e = &g_engine;
-    if (hipSetDevice(e->device) != hipSuccess) return E_MEMORY_ERROR;
+    SlotLease lease;
+    Engine *e = lease.e;
+    if (!e) return E_MEMORY_ERROR;
     const void *d_in = in;
     if (!device_input) {
         int st = stage_input(e, in, k * 384);
@@ -346,9 +406,9 @@ API uint64_t bls12_map_fp2_to_g2_gas(void) { return BLS12_MAP_FP2_TO_G2_GAS; }
 // ------------------------------------------------------------------ extensions
 API int eip2537_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_engine.ready) return g_engine.device == device || device < 0 ? 0 : E_MEMORY_ERROR;
+    if (g_nslots) return g_device == device || device < 0 ? 0 : E_MEMORY_ERROR;
     g_device_request = device;
-    return engine_init_locked() ? 0 : E_MEMORY_ERROR;
+    return device_select_locked() ? 0 : E_MEMORY_ERROR;
 }
 API int eip2537_hip_g1multiexp_dev(uint8_t out[128], const void *d_in, size_t n) { return n ? msm_entry<Fp>(out, d_in, n, true, false) : E_INVALID_LENGTH; }
 API int eip2537_hip_g2multiexp_dev(uint8_t out[256], const void *d_in, size_t n) { return n ? msm_entry<Fp2>(out, d_in, n, true, false) : E_INVALID_LENGTH; }
@@ -369,14 +429,15 @@ API int eip2537_hip_pairing_combine(uint8_t out[32], const uint8_t *partials, si
     return 0;
 }
 API void eip2537_hip_last_timing(float *pipeline_ms, float *dominant_kernel_ms) {
+    // the calling thread's last call if it made one, else the process's last call
     std::lock_guard<std::mutex> lk(g_mu);
-    if (pipeline_ms) *pipeline_ms = g_engine.last_kernel_ms;
-    if (dominant_kernel_ms) *dominant_kernel_ms = g_engine.last_accum_ms;
+    bool mine = t_last_kernel_ms != 0.f;
+    if (pipeline_ms) *pipeline_ms = mine ? t_last_kernel_ms : g_last_kernel_ms;
+    if (dominant_kernel_ms) *dominant_kernel_ms = mine ? t_last_accum_ms : g_last_accum_ms;
 }
 API int eip2537_hip_set_window(int c) {
     if (c != 0 && (c < 4 || c > 16)) return E_INVALID_LENGTH;
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_window_override = c;
+    g_window_override.store(c);
     return 0;
 }
 

@@ -153,9 +153,10 @@ def test_pairing_error_order(X, clib):
     assert call_x(X.pairing, bytes(383)) == (5, None)
 
 
-def test_concurrent_callers_are_serialised_correctly(X, clib):
+def test_concurrent_callers(X, clib):
     """The ABI is stateless and callers may be concurrent (cargo test threads, goroutines --
-    SURVEY.md 8b): eight threads hammer different precompiles through one engine."""
+    SURVEY.md 8b): 27 threads -- more than the library has engine slots -- hammer different
+    precompiles, one of them with a bad record whose error must stay on its own call."""
     import threading
     g1 = [clib.gen_msm_input("g1", 100 + 37 * t, A, B, 1000 + t) for t in range(4)]
     g2 = [clib.gen_msm_input("g2", 40 + 11 * t, A, B, 2000 + t) for t in range(2)]
@@ -163,6 +164,13 @@ def test_concurrent_callers_are_serialised_correctly(X, clib):
     want = [clib.call("bls12_g1multiexp", b) for b in g1] + [clib.call("bls12_g2multiexp", b) for b in g2] + \
            [clib.call("bls12_pairing", b) for b in pr]
     jobs = [(X.g1_multiexp, b) for b in g1] + [(X.g2_multiexp, b) for b in g2] + [(X.pairing, b) for b in pr]
+    broken = bytearray(g1[1])
+    broken[160 * 57 + 20] ^= 0x40                      # x of record 57 leaves the curve
+    jobs.append((X.g1_multiexp, bytes(broken)))
+    want.append(clib.call("bls12_g1multiexp", bytes(broken)))
+    assert want[-1][0] != 0
+    jobs = jobs * 3
+    want = want * 3
     bad = []
 
     def work(i):
