@@ -219,6 +219,9 @@ def main():
                        "records_total": n_total, "records_per_gpu": n_local,
                        "parallelism": "1 GPU" if world == 1 else "record-range shards x%d, RCCL all_gather of %d-byte partials" % (world, psz)},
             "bit_exact_vs_golden": parity,
+            # the reference Go bench's own unit (go/blst_eip2537_test.go:126-130), gas of the whole input
+            "mgas_per_s": X.gas({"g1msm": "g1multiexp", "g2msm": "g2multiexp", "pairing": "pairing"}[wl],
+                                n_total * REC[wl]) / (ms_per_step * 1e-3) / 1e6,
             "roofline": {"bound": "hbm", "kernel": KERNEL[wl], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": k_ms, "device_pipeline_ms": p_ms,
@@ -280,6 +283,7 @@ def main():
         dtp = (time.perf_counter() - t1) / reps
         sec = {"metric": "pairing_pairs_per_sec", "value": k / dtp, "unit": "pairs/s", "ms_per_check": dtp * 1e3,
                "pairs": k, "result_is_one": pout == bytes(31) + b"\x01",
+               "mgas_per_s": X.gas("pairing", k * 384) / dtp / 1e6,
                "roofline": {"bound": "hbm", "kernel": "k_pair_lines4", "achieved": 384 * k / (sum(kms) / reps * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 384 * k / (sum(kms) / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "traffic": None, "kernel_ms": sum(kms) / reps}}

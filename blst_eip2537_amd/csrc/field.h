@@ -41,52 +41,34 @@ HD bool eq(const Fp &a, const Fp &b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host paths: the same 48 bytes handled as 6 x 64-bit limbs.
 namespace hostfp {
-typedef unsigned __int128 u128;
+typedef unsigned long long ull;
 struct L6 { uint64_t w[6]; };
 inline L6 load(const Fp &a) { L6 r; memcpy(r.w, a.l, 48); return r; }
 inline Fp store(const L6 &a) { Fp r; memcpy(r.l, a.w, 48); return r; }
-inline L6 modulus() { static const uint32_t pw[12] = {K_P}; L6 r; memcpy(r.w, pw, 48); return r; }
+// K_P's 32-bit words paired into 64-bit limbs at compile time
+constexpr uint32_t kP32[12] = {K_P};
+constexpr uint64_t p64(int i) { return (uint64_t)kP32[2 * i] | ((uint64_t)kP32[2 * i + 1] << 32); }
+constexpr uint64_t kP64[6] = {p64(0), p64(1), p64(2), p64(3), p64(4), p64(5)};
+inline L6 modulus() { return L6{{kP64[0], kP64[1], kP64[2], kP64[3], kP64[4], kP64[5]}}; }
 inline L6 reduce_once(const L6 &t) {
-    const L6 p = modulus();
-    L6 d;
-    uint64_t borrow = 0;
-    for (int i = 0; i < 6; i++) {
-        u128 s = (u128)t.w[i] - p.w[i] - borrow;
-        d.w[i] = (uint64_t)s;
-        borrow = (uint64_t)(s >> 64) & 1;
-    }
-    const uint64_t keep_t = 0 - borrow;
+    ull d[6], borrow = 0;
+    for (int i = 0; i < 6; i++) d[i] = __builtin_subcll(t.w[i], kP64[i], borrow, &borrow);
     L6 r;
-    for (int i = 0; i < 6; i++) r.w[i] = (t.w[i] & keep_t) | (d.w[i] & ~keep_t);
+    for (int i = 0; i < 6; i++) r.w[i] = borrow ? t.w[i] : d[i];
     return r;
 }
 inline L6 add(const L6 &a, const L6 &b) {
     L6 t;
-    uint64_t c = 0;
-    for (int i = 0; i < 6; i++) {
-        u128 s = (u128)a.w[i] + b.w[i] + c;
-        t.w[i] = (uint64_t)s;
-        c = (uint64_t)(s >> 64);
-    }
-    return reduce_once(t);
+    ull c = 0;
+    for (int i = 0; i < 6; i++) t.w[i] = __builtin_addcll(a.w[i], b.w[i], c, &c);
+    return reduce_once(t);          // a + b < 2p < 2^384: no carry out
 }
 inline L6 sub(const L6 &a, const L6 &b) {
-    const L6 p = modulus();
-    L6 d;
-    uint64_t borrow = 0;
-    for (int i = 0; i < 6; i++) {
-        u128 s = (u128)a.w[i] - b.w[i] - borrow;
-        d.w[i] = (uint64_t)s;
-        borrow = (uint64_t)(s >> 64) & 1;
-    }
-    const uint64_t mask = 0 - borrow;
-    uint64_t c = 0;
+    ull d[6], borrow = 0, c = 0;
+    for (int i = 0; i < 6; i++) d[i] = __builtin_subcll(a.w[i], b.w[i], borrow, &borrow);
+    const uint64_t mask = 0 - (uint64_t)borrow;
     L6 r;
-    for (int i = 0; i < 6; i++) {
-        u128 s = (u128)d.w[i] + (p.w[i] & mask) + c;
-        r.w[i] = (uint64_t)s;
-        c = (uint64_t)(s >> 64);
-    }
+    for (int i = 0; i < 6; i++) r.w[i] = __builtin_addcll(d[i], kP64[i] & mask, c, &c);
     return r;
 }
 }  // namespace hostfp
@@ -276,30 +258,37 @@ HD Fp fp_sqr_cols28(const Fp &a) {
 }
 
 #if !defined(__HIP_DEVICE_COMPILE__)
-// Host: the same 48 bytes as 6 x 64-bit limbs.
+// Host: the same 48 bytes as 6 x 64-bit limbs.  Operand scanning with whole rows of 64x64->128
+// products (mulx with -mbmi2) and explicit add-with-carry chains; the running value stays below
+// 2p, so the seventh limb never overflows.  (The obvious "mac with a 128-bit accumulator" loop
+// compiled to ~2x the cycles: every step waited on the previous carry.)
+inline uint64_t host_mul_wide(uint64_t a, uint64_t b, unsigned long long *hi) {
+    unsigned __int128 p = (unsigned __int128)a * b;
+    *hi = (unsigned long long)(p >> 64);
+    return (uint64_t)p;
+}
 inline Fp fp_mul_limbs64(const Fp &a, const Fp &b) {
-    typedef unsigned __int128 u128;
-    const hostfp::L6 la = hostfp::load(a), lb = hostfp::load(b), lp = hostfp::modulus();
-    const uint64_t *A = la.w, *B = lb.w, *Pm = lp.w;
-    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef unsigned long long ull;
+    const hostfp::L6 la = hostfp::load(a), lb = hostfp::load(b);
+    const uint64_t *A = la.w, *B = lb.w, *Pm = hostfp::kP64;
+    ull t[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        uint64_t c = 0;
-        for (int j = 0; j < 6; j++) {
-            u128 s = (u128)A[j] * B[i] + t[j] + c;
-            t[j] = (uint64_t)s;
-            c = (uint64_t)(s >> 64);
-        }
-        t[6] = c;
-        uint64_t m = t[0] * K_N0_64;
-        u128 s = (u128)m * Pm[0] + t[0];
-        c = (uint64_t)(s >> 64);
-        for (int j = 1; j < 6; j++) {
-            s = (u128)m * Pm[j] + t[j] + c;
-            t[j - 1] = (uint64_t)s;
-            c = (uint64_t)(s >> 64);
-        }
-        t[5] = t[6] + c;
+        ull lo[6], hi[6], c = 0;
+        for (int j = 0; j < 6; j++) lo[j] = host_mul_wide(A[j], B[i], &hi[j]);
+        for (int j = 0; j < 6; j++) t[j] = __builtin_addcll(t[j], lo[j], c, &c);
+        t[6] = __builtin_addcll(t[6], 0, c, &c);
+        c = 0;
+        for (int j = 0; j < 6; j++) t[j + 1] = __builtin_addcll(t[j + 1], hi[j], c, &c);
+        const ull m = t[0] * K_N0_64;
+        for (int j = 0; j < 6; j++) lo[j] = host_mul_wide(m, Pm[j], &hi[j]);
+        c = 0;
+        (void)__builtin_addcll(t[0], lo[0], c, &c);           // low limb cancels by construction
+        for (int j = 1; j < 6; j++) t[j - 1] = __builtin_addcll(t[j], lo[j], c, &c);
+        t[5] = __builtin_addcll(t[6], 0, c, &c);
+        t[6] = 0;
+        c = 0;
+        for (int j = 0; j < 6; j++) t[j] = __builtin_addcll(t[j], hi[j], c, &c);
     }
     hostfp::L6 r;
     for (int i = 0; i < 6; i++) r.w[i] = t[i];
@@ -386,10 +375,32 @@ HD Fp2 fp2_sqr_body(const Fp2 &a) {
 // source was correct at -O1, with the 32-bit CIOS product, and in a smaller kernel) -- found by
 // the GPU parity tests, isolated by compiling that kernel alone at -O1 / -O3 and with either product.
 #if defined(__HIP_DEVICE_COMPILE__)
+// Fp2 product as three calls of the out-of-line Fp product.  Two Fp operands (24 dwords) travel in
+// argument VGPRs; two Fp2 operands (48 dwords) do not fit the 32 argument registers and go through
+// the stack, which made every fp2_mul_outlined call ~12 KB of scratch traffic per wave
+// (profiles/r01_pmc_pairing_2p12.csv: k_pair_tree wrote 2 GB per launch that way).
+static __device__ __forceinline__ Fp2 fp2_mul_regcall(const Fp2 &a, const Fp2 &b) {
+    Fp t0 = fp_mul_outlined(a.c0, b.c0);
+    Fp t1 = fp_mul_outlined(a.c1, b.c1);
+    Fp t2 = fp_mul_outlined(add(a.c0, a.c1), add(b.c0, b.c1));
+    return Fp2{sub(t0, t1), sub(sub(t2, t0), t1)};
+}
+static __device__ __forceinline__ Fp2 fp2_sqr_regcall(const Fp2 &a) {
+    Fp m = fp_mul_outlined(a.c0, a.c1);
+    return Fp2{fp_mul_outlined(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
+}
 static __device__ __noinline__ Fp2 fp2_mul_outlined(Fp2 a, Fp2 b) { return fp2_mul_body(a, b); }
 static __device__ __noinline__ Fp2 fp2_sqr_outlined(Fp2 a) { return fp2_sqr_body(a); }
+#ifndef EIP_FP2_POLICY
+#define EIP_FP2_POLICY 1
+#endif
+#if EIP_FP2_POLICY == 1
+HD Fp2 mul(const Fp2 &a, const Fp2 &b) { return fp2_mul_regcall(a, b); }
+HD Fp2 sqr(const Fp2 &a) { return fp2_sqr_regcall(a); }
+#else
 HD Fp2 mul(const Fp2 &a, const Fp2 &b) { return fp2_mul_outlined(a, b); }
 HD Fp2 sqr(const Fp2 &a) { return fp2_sqr_outlined(a); }
+#endif
 #else
 HD Fp2 mul(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
 HD Fp2 sqr(const Fp2 &a) { return fp2_sqr_body(a); }

@@ -316,6 +316,18 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
     if (len) perm[base[len] + local] = t;
 }
 
+// product used inside the multi-lane point operations: over Fp2 optionally the fully inlined body
+#ifndef EIP_G2_HOT_ACC
+#define EIP_G2_HOT_ACC 1
+#endif
+#ifndef EIP_G2_HOT_RED
+#define EIP_G2_HOT_RED 1
+#endif
+template <int HOT, class T> __device__ __forceinline__ T hmul(const T &a, const T &b) { return mul(a, b); }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> __device__ __forceinline__ Fp2 hmul<1, Fp2>(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
+#endif
+
 // ---- G2 accumulate, 2 lanes per task ----------------------------------------------------------
 // Over Fp2 a one-lane mixed addition keeps ~15 Fp2 values live (256 VGPR + 191 AGPR + scratch,
 // one wave per SIMD) and ran at a fifth of the G1 kernel's product rate.  Here a task owns two
@@ -325,21 +337,21 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
 __device__ __forceinline__ Xyzz<Fp2> madd2(const Xyzz<Fp2> &p, const Aff<Fp2> &q, int r, int gb) {
     if (is_inf(q)) return p;                                   // uniform in the pair of lanes
     if (is_inf(p)) return Xyzz<Fp2>{q.x, q.y, fp2_one(), fp2_one()};
-    Fp2 pr = mul(sel2(r, q.x, q.y), sel2(r, p.zz, p.zzz));
+    Fp2 pr = hmul<EIP_G2_HOT_ACC>(sel2(r, q.x, q.y), sel2(r, p.zz, p.zzz));
     const Fp2 U2 = shfl_from(pr, gb), S2 = shfl_from(pr, gb + 1);
     const Fp2 Pd = sub(U2, p.x), Rr = sub(S2, p.y);
     if (is_zero(Pd)) {
         if (is_zero(Rr)) return dbl_affine(q);
         return xyzz_inf<Fp2>();
     }
-    pr = mul(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
+    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
     const Fp2 PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1);
-    pr = mul(sel2(r, Pd, p.x), PP);
+    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, Pd, p.x), PP);
     const Fp2 PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1);
     const Fp2 X3 = sub(sub(RR, PPP), dbl(Q));
-    pr = mul(sel2(r, p.zz, p.y), sel2(r, PP, PPP));
+    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, p.zz, p.y), sel2(r, PP, PPP));
     const Fp2 ZZ3 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1);
-    pr = mul(sel2(r, Rr, p.zzz), sel2(r, sub(Q, X3), PPP));
+    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, Rr, p.zzz), sel2(r, sub(Q, X3), PPP));
     const Fp2 t0 = shfl_from(pr, gb), ZZZ3 = shfl_from(pr, gb + 1);
     return Xyzz<Fp2>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
@@ -454,32 +466,32 @@ template <class T> __device__ __forceinline__ Xyzz<T> add4(const Xyzz<T> &p, con
     const bool pinf = is_inf(p), qinf = is_inf(q);            // uniform in the group
     if (qinf) return p;
     if (pinf) return q;
-    T pr = mul(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
+    T pr = hmul<EIP_G2_HOT_RED>(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
     const T U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
     const T Pd = sub(U2, U1), Rr = sub(S2, S1);
     if (is_zero(Pd)) {                                         // same x: double or cancel (rare)
         if (is_zero(Rr)) return dbl(p);
         return xyzz_inf<T>();
     }
-    pr = mul(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
+    pr = hmul<EIP_G2_HOT_RED>(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
     const T PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
-    pr = mul(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
+    pr = hmul<EIP_G2_HOT_RED>(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
     const T PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
     const T X3 = sub(sub(RR, PPP), dbl(Q));
-    pr = mul(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
+    pr = hmul<EIP_G2_HOT_RED>(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
     const T t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // 2P (dbl-2008-s-1); infinity stays infinity
 template <class T> __device__ __forceinline__ Xyzz<T> dbl4(const Xyzz<T> &p, int r, int gb) {
     const T U = dbl(p.y);
-    T pr = mul(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
+    T pr = hmul<EIP_G2_HOT_RED>(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
     const T V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
     const T M = add(dbl(XX), XX);
-    pr = mul(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
+    pr = hmul<EIP_G2_HOT_RED>(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
     const T W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
     const T X3 = sub(MM, dbl(S));
-    pr = mul(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
+    pr = hmul<EIP_G2_HOT_RED>(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
     const T t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }

@@ -272,6 +272,20 @@ k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict_
 // Tower <-> w-power order:  [c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2] = [g0 g2 g4 g1 g3 g5].
 __device__ __forceinline__ int tower_slot(int sub) { return (sub & 1) * 3 + (sub >> 1); }
 
+#ifndef EIP_TREE_MUL
+#define EIP_TREE_MUL 2
+#endif
+__device__ __forceinline__ Fp2 tmul(const Fp2 &a, const Fp2 &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return mul(a, b);            // host pass only parses this
+#elif EIP_TREE_MUL == 1
+    return fp2_mul_regcall(a, b);
+#elif EIP_TREE_MUL == 2
+    return fp2_mul_body(a, b);
+#else
+    return mul(a, b);
+#endif
+}
 // out_k = sum_i a_i b_{k-i}, indices mod 6, times xi when the index wrapped
 __device__ __forceinline__ Fp2 grp_mul(const Fp2 &a, const Fp2 &b, int sub, int gbase) {
     Fp2 acc = fp2_zero();
@@ -281,7 +295,7 @@ __device__ __forceinline__ Fp2 grp_mul(const Fp2 &a, const Fp2 &b, int sub, int 
         if (wrap) j += 6;
         Fp2 ai = shfl_from(a, gbase + i);
         Fp2 bj = shfl_from(b, gbase + (j & 7));
-        Fp2 t = mul(ai, bj);
+        Fp2 t = tmul(ai, bj);
         Fp2 tx = mul_xi(t);
         acc = add(acc, wrap ? tx : t);
     }
@@ -294,9 +308,9 @@ __device__ __forceinline__ Fp2 grp_mul_line(const Fp2 &f, const LineRec &l, int 
     if (w2) j2 += 6;
     if (w3) j3 += 6;
     Fp2 f2 = shfl_from(f, gbase + (j2 & 7)), f3 = shfl_from(f, gbase + (j3 & 7));
-    Fp2 t0 = mul(f, l.a0);
-    Fp2 t2 = mul(f2, l.a1);
-    Fp2 t3 = mul(f3, l.a4);
+    Fp2 t0 = tmul(f, l.a0);
+    Fp2 t2 = tmul(f2, l.a1);
+    Fp2 t3 = tmul(f3, l.a4);
     Fp2 t2x = mul_xi(t2), t3x = mul_xi(t3);
     return add(add(t0, w2 ? t2x : t2), w3 ? t3x : t3);
 }

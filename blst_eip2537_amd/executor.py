@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libeip2537_hip.so")
+# EIP2537_HIP_LIB: load another build of the same library (kernel A/B runs); default is the in-tree one
+_SO = os.environ.get("EIP2537_HIP_LIB") or os.path.join(_HERE, "libeip2537_hip.so")
 
 ERROR_STRINGS = {
     0: "Success",
