@@ -504,6 +504,22 @@ template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &
     return acc;
 }
 
+// fold of lightly split buckets with 4-lane additions (G2: the one-lane chain of 1-7 Fp2 additions
+// on a few hundred lanes cost 0.19 ms at 2^16, where the 9-bit top window holds 128 records per bucket)
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_fold_small4(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+                  const uint32_t *__restrict__ split_counts) {
+    const uint32_t n = split_counts[0];
+    const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
+    for (uint32_t h = blockIdx.x * 64u + (threadIdx.x >> 2); h < n; h += gridDim.x * 64u) {   // uniform in the group
+        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        Xyzz<F> acc = partial[t0];
+        for (uint32_t t = t0 + 1; t < t1; t++) acc = add4(acc, partial[t], r, gb);
+        if (r == 0) partial[t0] = acc;
+    }
+}
+
 // grid (blocks, W); 256 threads = 64 four-lane groups, one segment of S buckets per group
 template <class F>
 __global__ void __launch_bounds__(256, 1)      // latency-bound chain: registers over occupancy
@@ -696,7 +712,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipEventRecord(e->ev_a, s));
     launch_accum(s, task_blocks, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
+    if (ReduceCfg<F>::kFourLane)
+        hipLaunchKernelGGL(k_msm_fold_small4<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
+    else
+        hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
     if (ReduceCfg<F>::kFourLane)
         hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
