@@ -26,6 +26,7 @@
 // inside a pair the reference's order G1 decode -> G1 subgroup -> G2 decode -> G2 subgroup.
 #include <algorithm>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
@@ -264,6 +265,96 @@ k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict_
     if (!in_sub && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
+// ---- line walk, 8 lanes per pair --------------------------------------------------------------
+// Between the two forms above: the four Fp2 products of a round go to four lane PAIRS, lane q of a
+// pair computing component q of its product by the schoolbook rule (c0 = a0 b0 - a1 b1,
+// c1 = a0 b1 + a1 b0: two Fp products per lane and no exchange inside the pair), so a doubling
+// step is 6 Fp-product times per lane instead of 9 (4 lanes) at half the waves of the 16-lane
+// form -- at 2^12 pairs that is 512 waves, which leaves SIMDs for the G1 membership kernel
+// running beside it (the 16-lane form fills every SIMD there and the two kernels serialise).
+__device__ __forceinline__ Prod4 fp2_products8(const Fp2 &u, const Fp2 &v, int q, int gbase) {
+    const Fp y1 = q ? v.c1 : v.c0, y2 = q ? v.c0 : v.c1;
+    const Fp m1 = fp_mul_cols28(u.c0, y1), m2 = fp_mul_cols28(u.c1, y2);
+    const Fp c = q ? add(m1, m2) : sub(m1, m2);
+    Prod4 o;
+    o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
+    o.r1 = Fp2{shfl_from(c, gbase + 2), shfl_from(c, gbase + 3)};
+    o.r2 = Fp2{shfl_from(c, gbase + 4), shfl_from(c, gbase + 5)};
+    o.r3 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
+    return o;
+}
+// same result as miller_dbl_step (pairing.h)
+__device__ __forceinline__ Line miller_dbl_step8(MillerT &T, int p, int q, int gbase) {
+    Prod4 pr = fp2_products8(sel4(p, T.x, T.y, T.z, T.y), sel4(p, T.x, T.y, T.z, T.z), q, gbase);
+    const Fp2 A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
+    const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
+    pr = fp2_products8(sel4(p, B, XB, E, E), sel4(p, B, XB, E, T.x), q, gbase);
+    const Fp2 C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
+    const Fp2 D = dbl(sub(sub(t, A), C));
+    const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
+    pr = fp2_products8(sel4(p, E, Z3, E, E), sel4(p, ZZ, ZZ, sub(D, X3), ZZ), q, gbase);
+    const Fp2 EZ = pr.r0, Z3ZZ = pr.r1, Ym = pr.r2;
+    Line l;
+    l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
+    l.a1 = neg(EZ);                   // -3X^2 Z^2
+    l.a4 = Z3ZZ;                      // 2YZ^3
+    T.x = X3;
+    T.y = sub(Ym, dbl(dbl(dbl(C))));
+    T.z = Z3;
+    return l;
+}
+
+__global__ void __launch_bounds__(64)
+k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+    __shared__ Aff<Fp> sP[8];
+    __shared__ Aff<Fp2> sQ[8];
+    const int lane = threadIdx.x & 63, sl = lane & 7, gbase = lane & ~7, gi = lane >> 3;
+    const int pidx = sl >> 1, q = sl & 1;
+    const uint32_t i = blockIdx.x * 8u + (threadIdx.x >> 3);
+    bool q_live = false, contributes = false;
+    MillerT T;
+    if (i < k) {                              // uniform within an 8-lane group
+        Aff<Fp> P;
+        Aff<Fp2> Q;
+        int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
+        int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
+        if (s2 != E_SUCCESS && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
+        q_live = s2 == E_SUCCESS && !is_inf(Q);
+        contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
+        if (sl == 0) { sP[gi] = P; sQ[gi] = Q; }
+        T = MillerT{Q.x, Q.y, fp2_one()};
+    }
+    __syncthreads();
+    if (i >= k) return;
+    if (!q_live) {
+        if (sl < 3) {
+            Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
+            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[sl] = v;
+        }
+        return;
+    }
+    const uint64_t z = K_Z_ABS;
+    int s = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        Line l = miller_dbl_step8(T, pidx, q, gbase);
+        store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+        s++;
+        if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
+            Aff<Fp2> Q = sQ[gi];
+            l = miller_add_step(T, Q);
+            store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+            s++;
+        }
+    }
+    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T      (blst_p2_affine_in_g2, reference :1051)
+    Aff<Fp2> Q = sQ[gi];
+    Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
+    Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
+    Fp2 zz = sqr(T.z);
+    bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
+    if (!in_sub && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+}
+
 // ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
 // In the product trees an Fp12 element g = sum_k g_k w^k (g_k in Fp2, w^6 = xi) lives in one
 // 8-lane group: lane `sub` (0..5) holds g_sub, lanes 6 and 7 idle.  A lane then needs ~24
@@ -377,7 +468,10 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     // 16 lanes per pair shorten the serial chain (small batches: 16 pairs 3.1 -> 2.7 ms) but replicate
     // the linear steps 4x more and put a wave on every SIMD at 2^12 pairs (3.4 vs 2.0 ms): by size
     const bool wide = k <= 2048;
-    const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : (uint32_t)((k + 15) / 16);
+    // 8 lanes per pair while walk + G1 membership waves still find a SIMD each (k/8 + k/64 <= ~1000)
+    static const int env_l8 = [] { const char *v = getenv("EIP2537_LINES8"); return v ? atoi(v) : 1; }();
+    const bool mid = !wide && k <= 7168 && env_l8;
+    const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : mid ? (uint32_t)((k + 7) / 8) : (uint32_t)((k + 15) / 16);
     // lines folded serially per 8-lane group: as few as possible while the whole grid (blocks x 68
     // steps) still fits in ONE round of 2 blocks per CU (512 slots); one block more than that and
     // the kernel takes two block-times (measured: 544 blocks 1.8 ms)
@@ -402,6 +496,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
     if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
+    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
     else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
     // A handful of pairs (the EVM's usual call: k = 2..4): the two product-tree launches are a fixed

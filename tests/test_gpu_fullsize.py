@@ -145,10 +145,11 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
     assert call_x(X.g2_multiexp, inp) == clib.call("bls12_g2multiexp", inp)
 
 
-def test_pairing_both_walk_kernels_ragged_sizes(X, clib):
-    """k <= 2048 runs the 16-lane line walk, larger batches the 4-lane one; ragged sizes around the
-    switch, each closed to the identity and broken by one, and an error in the last (partial) group."""
-    for k in (2047, 2049, 2100):
+def test_pairing_all_walk_kernels_ragged_sizes(X, clib):
+    """k <= 2048 runs the 16-lane line walk, k <= 7168 the 8-lane one, larger batches the 4-lane one;
+    ragged sizes around both switches, each closed to the identity and broken by one, and an error
+    in the last (partial) group."""
+    for k in (2047, 2049, 2100, 7167, 7169, 7203):
         good, bad = _pairing_batch(X, k, 0), _pairing_batch(X, k, 1)
         assert call_x(X.pairing, good) == (0, bytes(31) + b"\x01"), k
         assert call_x(X.pairing, bad) == (0, bytes(32)), k
