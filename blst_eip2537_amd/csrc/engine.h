@@ -53,7 +53,7 @@ struct MsmPlan {
     uint32_t max_tasks;
     uint64_t max_entries;
 };
-MsmPlan msm_make_plan(uint32_t n, int c_override);
+MsmPlan msm_make_plan(uint32_t n, int c_override, bool g2);
 
 // Device pipelines.  `d_in` is the EIP-encoded record stream resident in HBM (4-byte aligned).
 // On success returns 0 and writes the projective partial sum (XYZZ, Montgomery limbs: 48 words

@@ -39,11 +39,24 @@ namespace eip {
 
 struct Task { uint32_t start, len; };
 
-MsmPlan msm_make_plan(uint32_t n, int c_override) {
+// Window width measured best per size class on MI355X (profiles/r01_window_sweep.txt).  The work
+// model below (products per record-window and per bucket) ranks plans well once the kernels are
+// throughput-bound (n >= 2^17) but not below, where the call is a sum of serial chains: the
+// longest bucket of the accumulate and ~2S + 2 log2(buckets) + 10 point operations of the reduce.
+// There the widths whose top window needs no merging (c = 5, 8, 13, 16 leave 6/8/9/16 top bits)
+// win by 15-25 % over their neighbours.
+static int msm_measured_width(uint32_t n, bool g2) {
+    if (n <= 64) return 5;
+    if (n <= 2048) return 8;
+    if (g2) return n <= (1u << 17) ? 13 : 0;      // larger G2 inputs: not measured, use the model
+    return n <= 65536 ? 13 : 16;
+}
+MsmPlan msm_make_plan(uint32_t n, int c_override, bool g2) {
+    if (!c_override) c_override = msm_measured_width(n, g2);
     MsmPlan best{};
     double best_cost = 1e300;
     for (int c = 4; c <= 16; c++) {
-        if (c_override && c != c_override) continue;
+        if (c_override > 0 && c != c_override) continue;      // -1: the work model alone
         MsmPlan pl{};
         pl.n = n;
         pl.c = c;
@@ -61,6 +74,9 @@ MsmPlan msm_make_plan(uint32_t n, int c_override) {
         double cost = (double)n * pl.W * 10.0 + (double)pl.NB * 30.0;
         if (cost < best_cost) { best_cost = cost; best = pl; }
     }
+    // a forced width with no valid plan (c = 14: the merged top window would need 18 bits) falls
+    // back to the planner's own choice rather than returning an empty plan
+    if (best_cost == 1e300 && c_override) return msm_make_plan(n, -1, g2);
     MsmPlan &pl = best;
     pl.L = 64;                                   // refined in msm_device_t
     pl.S = 16;                                   // refined per field in msm_device_t
@@ -628,7 +644,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         fprintf(stderr, "[eip2537_hip] device input must be 4-byte aligned\n");
         return E_MEMORY_ERROR;
     }
-    MsmPlan pl = msm_make_plan((uint32_t)n, c_override);
+    MsmPlan pl = msm_make_plan((uint32_t)n, c_override, ReduceCfg<F>::kFourLane);
     if (pl.max_entries >= (1ull << 32)) return E_MEMORY_ERROR;
     // task length limit L = 2^lshift: at least 64, and at least twice the mean bucket load so that
     // split buckets stay the exception (they cost an extra fold pass)
