@@ -184,3 +184,16 @@ def test_concurrent_callers(X, clib):
     for t in ths:
         t.join()
     assert not bad
+
+
+def test_forced_window_width_without_a_valid_plan_falls_back(X, clib):
+    """eip2537_hip_set_window is a bench / sweep knob; c = 14 has no valid plan (its merged top
+    window would need 18 bits) and used to leave an empty plan (SIGFPE in the host code)."""
+    inp = clib.gen_msm_input("g1", 300, A, B, 77)
+    want = clib.call("bls12_g1multiexp", inp)
+    try:
+        for c in (14, 4, 16, 0):
+            X.set_window(c)
+            assert call_x(X.g1_multiexp, inp) == want, c
+    finally:
+        X.set_window(0)
