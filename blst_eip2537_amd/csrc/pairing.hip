@@ -424,8 +424,13 @@ k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, gbase = lane & ~7;
     const uint32_t g = blockIdx.x * 32u + (threadIdx.x >> 3);
+    // the group's first line seeds the accumulator (a0 + a1 w^2 + a4 w^3 in w-power slots 0, 2, 3)
     Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
-    for (uint32_t j = 0; j < group_lines; j++) {
+    if ((size_t)g * group_lines < k) {
+        const LineRec l = lines[(size_t)s * k + (size_t)g * group_lines];
+        acc = sub == 0 ? l.a0 : sub == 2 ? l.a1 : sub == 3 ? l.a4 : fp2_zero();
+    }
+    for (uint32_t j = 1; j < group_lines; j++) {
         const uint32_t i = g * group_lines + j;
         if (i < k) {
             LineRec l = lines[(size_t)s * k + i];
@@ -435,12 +440,13 @@ k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk
     wave_group_product(acc, lane, sub, gbase);
     if (lane < 6) sm[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && lane < 8) {
-        for (int w = 1; w < 4; w++) {
-            Fp2 partner = sm[w][sub < 6 ? sub : 0];
-            acc = grp_mul(acc, partner, sub, 0);
-        }
-        if (sub < 6) blk_out[((size_t)s * gridDim.x + blockIdx.x) * 6 + tower_slot(sub)] = acc;
+    if (wave == 0 && lane < 16) {
+        // two levels: groups 0 and 1 of wave 0 take (wave 0 x wave 1) and (wave 2 x wave 3), then group 0 joins them
+        const int gq = lane >> 3, sidx = sub < 6 ? sub : 0;
+        acc = grp_mul(sm[2 * gq][sidx], sm[2 * gq + 1][sidx], sub, gbase);
+        const Fp2 partner = shfl_from(acc, 8 + sub);
+        if (gq == 0) acc = grp_mul(acc, partner, sub, 0);
+        if (lane < 6) blk_out[((size_t)s * gridDim.x + blockIdx.x) * 6 + tower_slot(lane)] = acc;
     }
 }
 
@@ -449,8 +455,13 @@ __global__ void __launch_bounds__(64)
 k_pair_tree2(const Fp2 *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ step_out) {
     const int s = blockIdx.x;
     const int lane = threadIdx.x, sub = lane & 7, gbase = lane & ~7, gi = lane >> 3;
+    // each group's first element seeds its accumulator (lanes 6, 7 of a group carry zeros)
     Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
-    for (uint32_t b = gi; b < nblk; b += 8) {
+    if ((uint32_t)gi < nblk) {
+        acc = blk_out[((size_t)s * nblk + gi) * 6 + tower_slot(sub < 6 ? sub : 0)];
+        if (sub >= 6) acc = fp2_zero();
+    }
+    for (uint32_t b = gi + 8; b < nblk; b += 8) {
         Fp2 partner = blk_out[((size_t)s * nblk + b) * 6 + tower_slot(sub < 6 ? sub : 0)];
         acc = grp_mul(acc, partner, sub, gbase);
     }
