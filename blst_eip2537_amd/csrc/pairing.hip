@@ -94,21 +94,20 @@ __device__ __forceinline__ Line miller_dbl_step4(MillerT &T, int r, int gbase) {
     T.z = Z3;
     return l;
 }
-// scale (a1, a4) by (xP, yP): four Fp products, one per lane; then lanes 0..2 store a0, a1, a4
-__device__ __forceinline__ void store_line4(LineRec *dst, const Line &l, const Aff<Fp> *P, bool contributes, int r, int gbase) {
-    Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
-    Fp q = mul(w, r < 2 ? P->x : P->y);
-    Fp2 a1{shfl_from(q, gbase), shfl_from(q, gbase + 1)}, a4{shfl_from(q, gbase + 2), shfl_from(q, gbase + 3)};
-    Fp2 v = r == 0 ? l.a0 : (r == 1 ? a1 : a4);
-    if (!contributes) v = r == 0 ? fp2_one() : fp2_zero();
-    if (r < 3) (&dst->a0)[r] = v;
+// lanes 0..2 of the pair's group store a0, a1, a4 UNSCALED: multiplying (a1, a4) by (xP, yP) is left
+// to the product tree (throughput-rich), which takes one Fp product and ~800 instructions per step
+// off the walk's serial chain
+__device__ __forceinline__ void store_line_raw(LineRec *dst, const Line &l, bool contributes, int sub_lane) {
+    Fp2 v = sub_lane == 0 ? l.a0 : (sub_lane == 1 ? l.a1 : l.a4);
+    if (!contributes) v = sub_lane == 0 ? fp2_one() : fp2_zero();
+    if (sub_lane < 3) (&dst->a0)[sub_lane] = v;
 }
 
 __global__ void __launch_bounds__(64)
-k_pair_lines4(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+k_pair_lines4(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, Aff<Fp> *__restrict__ pmont,
+              unsigned long long *err) {
     // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
     // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
-    __shared__ Aff<Fp> sP[16];
     __shared__ Aff<Fp2> sQ[16];
     const int lane = threadIdx.x & 63, r = lane & 3, gbase = lane & ~3, gi = lane >> 2;
     const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
@@ -122,7 +121,7 @@ k_pair_lines4(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__
         if (s2 != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
         q_live = s2 == E_SUCCESS && !is_inf(Q);
         contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-        if (r == 0) { sP[gi] = P; sQ[gi] = Q; }
+        if (r == 0) { pmont[i] = P; sQ[gi] = Q; }
         T = MillerT{Q.x, Q.y, fp2_one()};
     }
     __syncthreads();
@@ -138,12 +137,12 @@ k_pair_lines4(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
         Line l = miller_dbl_step4(T, r, gbase);
-        store_line4(&lines[(size_t)s * k + i], l, &sP[gi], contributes, r, gbase);
+        store_line_raw(&lines[(size_t)s * k + i], l, contributes, r);
         s++;
         if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the 4 lanes
             Aff<Fp2> Q = sQ[gi];
             l = miller_add_step(T, Q);
-            store_line4(&lines[(size_t)s * k + i], l, &sP[gi], contributes, r, gbase);
+            store_line_raw(&lines[(size_t)s * k + i], l, contributes, r);
             s++;
         }
     }
@@ -200,22 +199,11 @@ __device__ __forceinline__ Line miller_dbl_step16(MillerT &T, int p, int q, int 
     T.z = Z3;
     return l;
 }
-// scale (a1, a4) by (xP, yP): four Fp products on lanes 0..3; then lanes 0..2 store a0, a1, a4
-__device__ __forceinline__ void store_line16(LineRec *dst, const Line &l, const Aff<Fp> *P, bool contributes, int sub_lane, int gbase) {
-    const int r = sub_lane & 3;
-    Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
-    Fp qv = fp_mul_cols28(w, r < 2 ? P->x : P->y);
-    Fp2 a1{shfl_from(qv, gbase), shfl_from(qv, gbase + 1)}, a4{shfl_from(qv, gbase + 2), shfl_from(qv, gbase + 3)};
-    Fp2 v = sub_lane == 0 ? l.a0 : (sub_lane == 1 ? a1 : a4);
-    if (!contributes) v = sub_lane == 0 ? fp2_one() : fp2_zero();
-    if (sub_lane < 3) (&dst->a0)[sub_lane] = v;
-}
-
 __global__ void __launch_bounds__(64)
-k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, Aff<Fp> *__restrict__ pmont,
+              unsigned long long *err) {
     // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
     // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
-    __shared__ Aff<Fp> sP[4];
     __shared__ Aff<Fp2> sQ[4];
     const int lane = threadIdx.x & 63, sl = lane & 15, gbase = lane & ~15, gi = lane >> 4;
     const int pidx = sl / 3 < 3 ? sl / 3 : 3, q = sl - 3 * (sl / 3), tb = gbase + 3 * pidx;   // lanes 12..15 shadow product 3
@@ -230,7 +218,7 @@ k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict_
         if (s2 != E_SUCCESS && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
         q_live = s2 == E_SUCCESS && !is_inf(Q);
         contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-        if (sl == 0) { sP[gi] = P; sQ[gi] = Q; }
+        if (sl == 0) { pmont[i] = P; sQ[gi] = Q; }
         T = MillerT{Q.x, Q.y, fp2_one()};
     }
     __syncthreads();
@@ -246,12 +234,12 @@ k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict_
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
         Line l = miller_dbl_step16(T, pidx, q, tb, gbase);
-        store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+        store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
         s++;
         if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
             Aff<Fp2> Q = sQ[gi];
             l = miller_add_step(T, Q);
-            store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+            store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
             s++;
         }
     }
@@ -305,8 +293,8 @@ __device__ __forceinline__ Line miller_dbl_step8(MillerT &T, int p, int q, int g
 }
 
 __global__ void __launch_bounds__(64)
-k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
-    __shared__ Aff<Fp> sP[8];
+k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, Aff<Fp> *__restrict__ pmont,
+              unsigned long long *err) {
     __shared__ Aff<Fp2> sQ[8];
     const int lane = threadIdx.x & 63, sl = lane & 7, gbase = lane & ~7, gi = lane >> 3;
     const int pidx = sl >> 1, q = sl & 1;
@@ -321,7 +309,7 @@ k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__
         if (s2 != E_SUCCESS && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
         q_live = s2 == E_SUCCESS && !is_inf(Q);
         contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-        if (sl == 0) { sP[gi] = P; sQ[gi] = Q; }
+        if (sl == 0) { pmont[i] = P; sQ[gi] = Q; }
         T = MillerT{Q.x, Q.y, fp2_one()};
     }
     __syncthreads();
@@ -337,12 +325,12 @@ k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
         Line l = miller_dbl_step8(T, pidx, q, gbase);
-        store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+        store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
         s++;
         if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
             Aff<Fp2> Q = sQ[gi];
             l = miller_add_step(T, Q);
-            store_line16(&lines[(size_t)s * k + i], l, &sP[gi], contributes, sl, gbase);
+            store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
             s++;
         }
     }
@@ -393,6 +381,18 @@ __device__ __forceinline__ Fp2 grp_mul(const Fp2 &a, const Fp2 &b, int sub, int 
     }
     return acc;
 }
+// (a1, a4) of a stored line times (xP, yP): four Fp products on lanes 0..3 of the group
+__device__ __forceinline__ void scale_line(LineRec &l, const Aff<Fp> &P, int sub, int gbase) {
+    const int r = sub & 3;
+    const Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const Fp q = fp_mul_cols28(w, r < 2 ? P.x : P.y);
+#else
+    const Fp q = mul(w, r < 2 ? P.x : P.y);
+#endif
+    l.a1 = Fp2{shfl_from(q, gbase), shfl_from(q, gbase + 1)};
+    l.a4 = Fp2{shfl_from(q, gbase + 2), shfl_from(q, gbase + 3)};
+}
 // f * (a0 + a1 w^2 + a4 w^3)
 __device__ __forceinline__ Fp2 grp_mul_line(const Fp2 &f, const LineRec &l, int sub, int gbase) {
     int j2 = sub - 2, j3 = sub - 3;
@@ -419,7 +419,8 @@ __device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, 
 // grid (blocks, 68 steps), 256 threads = 32 groups: each group folds `group_lines` lines of its
 // step into a dense element, then wave tree (shuffles) and an LDS step across the 4 waves.
 __global__ void __launch_bounds__(256)
-k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk_out, uint32_t group_lines) {
+k_pair_tree(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__ pmont, uint32_t k, Fp2 *__restrict__ blk_out,
+            uint32_t group_lines) {
     __shared__ Fp2 sm[4][6];
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, gbase = lane & ~7;
@@ -427,13 +428,15 @@ k_pair_tree(const LineRec *__restrict__ lines, uint32_t k, Fp2 *__restrict__ blk
     // the group's first line seeds the accumulator (a0 + a1 w^2 + a4 w^3 in w-power slots 0, 2, 3)
     Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
     if ((size_t)g * group_lines < k) {
-        const LineRec l = lines[(size_t)s * k + (size_t)g * group_lines];
+        LineRec l = lines[(size_t)s * k + (size_t)g * group_lines];
+        scale_line(l, pmont[(size_t)g * group_lines], sub, gbase);
         acc = sub == 0 ? l.a0 : sub == 2 ? l.a1 : sub == 3 ? l.a4 : fp2_zero();
     }
     for (uint32_t j = 1; j < group_lines; j++) {
         const uint32_t i = g * group_lines + j;
         if (i < k) {
             LineRec l = lines[(size_t)s * k + i];
+            scale_line(l, pmont[i], sub, gbase);
             acc = grp_mul_line(acc, l, sub, gbase);
         }
     }
@@ -490,10 +493,12 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     const uint32_t group_lines = (uint32_t)std::max<size_t>(1, (k + 32 * max_blocks_per_step - 1) / (32 * max_blocks_per_step));
     const uint32_t tree_blocks = (uint32_t)((k + 32 * group_lines - 1) / (32 * group_lines));
     HIPCHK(e->misc.reserve(64));
+    HIPCHK(e->pts.reserve(k * sizeof(Aff<Fp>)));
     HIPCHK(e->partial.reserve((size_t)kSteps * k * sizeof(LineRec)));
     HIPCHK(e->winout.reserve(((size_t)kSteps * tree_blocks + kSteps) * sizeof(Fp12)));
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *lines = reinterpret_cast<LineRec *>(e->partial.p);
+    auto *pmont = reinterpret_cast<Aff<Fp> *>(e->pts.p);               // P of every pair, Montgomery form
     auto *blk_out = reinterpret_cast<Fp2 *>(e->winout.p);                 // [step][block] tower-layout Fp12
     auto *step_out = blk_out + (size_t)kSteps * tree_blocks * 6;           // [step] Fp12
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
@@ -506,15 +511,15 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipLaunchKernelGGL(k_pair_check_g1, dim3(blocks), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
-    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
-    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
-    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, err);
+    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
+    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
+    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
     // A handful of pairs (the EVM's usual call: k = 2..4): the two product-tree launches are a fixed
     // ~0.42 ms chain, more than the host needs to fold k sparse lines per step into F itself.
     const bool host_fold = k <= kHostFoldPairs;
     if (!host_fold) {
-        hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, (uint32_t)k, blk_out, group_lines);
+        hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k, blk_out, group_lines);
         hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
     }
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
@@ -524,9 +529,12 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     unsigned long long herr = 0;
     std::vector<Fp12> L(host_fold ? 0 : kSteps);
     std::vector<LineRec> hl(host_fold ? (size_t)kSteps * k : 0);
+    std::vector<Aff<Fp>> hp(host_fold ? k : 0);
     HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
-    if (host_fold) HIPCHK(hipMemcpyAsync(hl.data(), lines, hl.size() * sizeof(LineRec), hipMemcpyDeviceToHost, s));
-    else HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
+    if (host_fold) {
+        HIPCHK(hipMemcpyAsync(hl.data(), lines, hl.size() * sizeof(LineRec), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hp.data(), pmont, hp.size() * sizeof(Aff<Fp>), hipMemcpyDeviceToHost, s));
+    } else HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
@@ -541,7 +549,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
         if (!host_fold) { F = mul(F, L[step]); return; }
         for (size_t i = 0; i < k; i++) {
             const LineRec &l = hl[(size_t)step * k + i];
-            F = mul_by_014(F, l.a0, l.a1, l.a4);
+            F = mul_by_014(F, l.a0, mul_fp(l.a1, hp[i].x), mul_fp(l.a4, hp[i].y));
         }
     };
     for (int bit = 62; bit >= 0; bit--) {
