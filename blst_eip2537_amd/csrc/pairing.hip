@@ -381,6 +381,58 @@ __device__ __forceinline__ Fp2 grp_mul(const Fp2 &a, const Fp2 &b, int sub, int 
     }
     return acc;
 }
+// Dense product with 24 instead of 36 Fp2 products, three per lane on all 8 lanes.  In tower terms
+// g = a0 + a1 w with a0 = (g0, g2, g4), a1 = (g1, g3, g5) in Fp6 = Fp2[v]/(v^3 - xi), v = w^2:
+//   lane pair p computes one Fp6 product  (p = 0: a0 b0,  1: a1 b1,  2: a0 b1,  3: a1 b0)
+//   by Karatsuba: lane q = 0 the x_i y_i, lane q = 1 the (x_i + x_j)(y_i + y_j); the two lanes swap
+//   their products and both form z = x y; then  c0 = a0 b0 + v (a1 b1),  c1 = a0 b1 + a1 b0.
+// Out of line on purpose: one copy of the three inlined Fp2 products serves every call site, and a
+// block makes only ~10 of these calls (the stack-argument cost that ruled this out for the
+// per-line products does not matter here).
+#ifndef EIP_TREE_KARATSUBA
+#define EIP_TREE_KARATSUBA 1
+#endif
+template <int CALLER> static __device__ __noinline__ Fp2 grp_mul_k(Fp2 a, Fp2 b, int slot, int gbase) {
+    const int p = slot >> 1, q = slot & 1;
+    const int px = p & 1, py = (p == 1 || p == 2) ? 1 : 0;
+    // round r multiplies x_r y_r (q = 0) or (x_r + x_r')(y_r + y_r') with r' = r + 1 mod 3 (q = 1); the
+    // operands are gathered per round (registers: this function must fit beside a second wave)
+    Fp2 m[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int r2 = r == 2 ? 0 : r + 1;
+        const Fp2 xr = shfl_from(a, gbase + 2 * r + px), xs = shfl_from(a, gbase + 2 * r2 + px);
+        const Fp2 yr = shfl_from(b, gbase + 2 * r + py), ys = shfl_from(b, gbase + 2 * r2 + py);
+        m[r] = mul(sel2(q, xr, add(xr, xs)), sel2(q, yr, add(yr, ys)));       // three register-argument Fp calls
+    }
+    const int partner = gbase + (slot ^ 1);
+    const Fp2 n0 = shfl_from(m[0], partner), n1 = shfl_from(m[1], partner), n2 = shfl_from(m[2], partner);
+    const Fp2 t0 = sel2(q, m[0], n0), t1 = sel2(q, m[1], n1), t2 = sel2(q, m[2], n2);
+    const Fp2 s01 = sel2(q, n0, m[0]), s12 = sel2(q, n1, m[1]), s02 = sel2(q, n2, m[2]);
+    const Fp2 z0 = add(t0, mul_xi(sub(sub(s12, t1), t2)));
+    const Fp2 z1 = add(sub(sub(s01, t0), t1), mul_xi(t2));
+    const Fp2 z2 = add(sub(sub(s02, t0), t2), t1);
+    // lane q of a pair publishes z_q in out1; z2 travels on its own
+    const Fp2 out1 = sel2(q, z0, z1);
+    // slot k = 2i (+1): even  c0_i = (a0 b0)_i + (v a1 b1)_i,  v (z0, z1, z2) = (xi z2, z0, z1);  odd  c1_i = (a0 b1)_i + (a1 b0)_i
+    const int k = slot < 6 ? slot : 0, i = k >> 1, odd = k & 1;
+    const int pa = odd ? 2 : 0, pb = odd ? 3 : 1;
+    const int cb = odd ? i : (i == 0 ? 2 : i - 1);
+    const Fp2 fa1 = shfl_from(out1, gbase + 2 * pa + (i == 1 ? 1 : 0)), fa2 = shfl_from(z2, gbase + 2 * pa);
+    const Fp2 fb1 = shfl_from(out1, gbase + 2 * pb + (cb == 1 ? 1 : 0)), fb2 = shfl_from(z2, gbase + 2 * pb);
+    const Fp2 first = i == 2 ? fa2 : fa1;
+    Fp2 second = cb == 2 ? fb2 : fb1;
+    const Fp2 sxi = mul_xi(second);
+    if (!odd && i == 0) second = sxi;
+    return add(first, second);
+}
+template <int CALLER> __device__ __forceinline__ Fp2 grp_mul_dense(const Fp2 &a, const Fp2 &b, int sub, int gbase) {
+#if EIP_TREE_KARATSUBA && defined(__HIP_DEVICE_COMPILE__)
+    return grp_mul_k<CALLER>(a, b, sub, gbase);      // one copy per kernel: it inherits that kernel's register budget
+#else
+    return grp_mul(a, b, sub, gbase);
+#endif
+}
 // (a1, a4) of a stored line times (xP, yP): four Fp products on lanes 0..3 of the group
 __device__ __forceinline__ void scale_line(LineRec &l, const Aff<Fp> &P, int sub, int gbase) {
     const int r = sub & 3;
@@ -407,18 +459,18 @@ __device__ __forceinline__ Fp2 grp_mul_line(const Fp2 &f, const LineRec &l, int 
     return add(add(t0, w2 ? t2x : t2), w3 ? t3x : t3);
 }
 // product of the 8 groups of a wave, left in group 0
-__device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, int gbase) {
+template <int CALLER> __device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, int gbase) {
     const int gi = lane >> 3;
     for (int step = 1; step < 8; step <<= 1) {
         Fp2 partner = shfl_from(acc, (lane + 8 * step) & 63);
-        if ((gi & (2 * step - 1)) == 0) acc = grp_mul(acc, partner, sub, gbase);
+        if ((gi & (2 * step - 1)) == 0) acc = grp_mul_dense<CALLER>(acc, partner, sub, gbase);
     }
 }
 
 
 // grid (blocks, 68 steps), 256 threads = 32 groups: each group folds `group_lines` lines of its
 // step into a dense element, then wave tree (shuffles) and an LDS step across the 4 waves.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)     // two blocks per CU: the grid is sized to one such round
 k_pair_tree(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__ pmont, uint32_t k, Fp2 *__restrict__ blk_out,
             uint32_t group_lines) {
     __shared__ Fp2 sm[4][6];
@@ -440,15 +492,15 @@ k_pair_tree(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__ pmont
             acc = grp_mul_line(acc, l, sub, gbase);
         }
     }
-    wave_group_product(acc, lane, sub, gbase);
+    wave_group_product<0>(acc, lane, sub, gbase);
     if (lane < 6) sm[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && lane < 16) {
         // two levels: groups 0 and 1 of wave 0 take (wave 0 x wave 1) and (wave 2 x wave 3), then group 0 joins them
         const int gq = lane >> 3, sidx = sub < 6 ? sub : 0;
-        acc = grp_mul(sm[2 * gq][sidx], sm[2 * gq + 1][sidx], sub, gbase);
+        acc = grp_mul_dense<0>(sm[2 * gq][sidx], sm[2 * gq + 1][sidx], sub, gbase);
         const Fp2 partner = shfl_from(acc, 8 + sub);
-        if (gq == 0) acc = grp_mul(acc, partner, sub, 0);
+        if (gq == 0) acc = grp_mul_dense<0>(acc, partner, sub, 0);
         if (lane < 6) blk_out[((size_t)s * gridDim.x + blockIdx.x) * 6 + tower_slot(lane)] = acc;
     }
 }
@@ -466,9 +518,9 @@ k_pair_tree2(const Fp2 *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ s
     }
     for (uint32_t b = gi + 8; b < nblk; b += 8) {
         Fp2 partner = blk_out[((size_t)s * nblk + b) * 6 + tower_slot(sub < 6 ? sub : 0)];
-        acc = grp_mul(acc, partner, sub, gbase);
+        acc = grp_mul_dense<1>(acc, partner, sub, gbase);
     }
-    wave_group_product(acc, lane, sub, gbase);
+    wave_group_product<1>(acc, lane, sub, gbase);
     if (lane < 6) step_out[(size_t)s * 6 + tower_slot(lane)] = acc;
 }
 
