@@ -46,7 +46,6 @@ namespace eip {
     } while (0)
 
 static constexpr int kPairWords = 96;    // 384 bytes
-static constexpr size_t kHostFoldPairs = 4;   // up to this many pairs the host folds the lines itself
 static constexpr int kSteps = 68;        // 63 doublings + 5 additions for |z| = 0xd201000000010000
 
 struct LineRec { Fp2 a0, a1, a4; };      // l = a0 + a1 v + a4 v w   (a1, a4 already scaled by xP, yP)
@@ -567,26 +566,16 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
     else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    // A handful of pairs (the EVM's usual call: k = 2..4): the two product-tree launches are a fixed
-    // ~0.42 ms chain, more than the host needs to fold k sparse lines per step into F itself.
-    const bool host_fold = k <= kHostFoldPairs;
-    if (!host_fold) {
-        hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k, blk_out, group_lines);
-        hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
-    }
+    hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k, blk_out, group_lines);
+    hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
     unsigned long long herr = 0;
-    std::vector<Fp12> L(host_fold ? 0 : kSteps);
-    std::vector<LineRec> hl(host_fold ? (size_t)kSteps * k : 0);
-    std::vector<Aff<Fp>> hp(host_fold ? k : 0);
+    std::vector<Fp12> L(kSteps);
     HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
-    if (host_fold) {
-        HIPCHK(hipMemcpyAsync(hl.data(), lines, hl.size() * sizeof(LineRec), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hp.data(), pmont, hp.size() * sizeof(Aff<Fp>), hipMemcpyDeviceToHost, s));
-    } else HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
@@ -594,20 +583,14 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     if (herr != ~0ull) return (int)(herr & 7ull);
 
     // F = (...((L_0)^2 L_1)^2 ...): square before every doubling step, conjugate because z < 0
+    // (folding the k sparse lines of a step on the host instead of launching the tree was tried for
+    // k <= 4: it won while the tree cost 0.42 ms, and lost -- 2.8 vs 2.4 ms at k = 4 -- once it did not)
     Fp12 F = fp12_one();
     const uint64_t z = K_Z_ABS;
     int si = 0;
-    auto fold_step = [&](int step) {
-        if (!host_fold) { F = mul(F, L[step]); return; }
-        for (size_t i = 0; i < k; i++) {
-            const LineRec &l = hl[(size_t)step * k + i];
-            F = mul_by_014(F, l.a0, mul_fp(l.a1, hp[i].x), mul_fp(l.a4, hp[i].y));
-        }
-    };
     for (int bit = 62; bit >= 0; bit--) {
-        F = sqr(F);
-        fold_step(si++);
-        if ((z >> bit) & 1ull) fold_step(si++);
+        F = mul(sqr(F), L[si++]);
+        if ((z >> bit) & 1ull) F = mul(F, L[si++]);
     }
     F = conj(F);
     memcpy(ml_words, &F, sizeof F);
