@@ -46,10 +46,9 @@ struct Task { uint32_t start, len; };
 // There the widths whose top window needs no merging (c = 5, 8, 13, 16 leave 6/8/9/16 top bits)
 // win by 15-25 % over their neighbours.
 static int msm_measured_width(uint32_t n, bool g2) {
-    if (n <= 64) return 5;
-    if (n <= 2048) return 8;
+    if (n < 2048) return 8;
     if (g2) return n <= (1u << 17) ? 13 : 0;      // larger G2 inputs: not measured, use the model
-    return n <= 65536 ? 13 : 16;
+    return n <= (1u << 17) ? 13 : 16;
 }
 MsmPlan msm_make_plan(uint32_t n, int c_override, bool g2) {
     if (!c_override) c_override = msm_measured_width(n, g2);
@@ -634,6 +633,7 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, const Aff<Fp2> *pt
                          const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
     hipLaunchKernelGGL(k_msm_accum2, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
+static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; };
 template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; };
 
@@ -658,8 +658,12 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     //  G2: 4 lanes per segment, 64 segments per block; the shortest chain that still places at
     //      most one wave on every SIMD (<= ~232 working blocks on 256 CUs: a second wave on a SIMD
     //      doubles the latency of both and the kernel waits for the slowest)
-    const uint32_t seg_per_block = ReduceCfg<F>::kFourLane ? 64u : 256u;
-    if (ReduceCfg<F>::kFourLane) pl.S = std::max(1u, (pl.NB + 64u * 232u - 1u) / (64u * 232u));
+    // G1 takes the 4-lane form too while the bucket count is small (c <= 13 plans): few waves, so the
+    // shorter chain wins (2^7 .. 2^16 records: 0.61 -> 0.41 ms .. 1.76 -> 1.45 ms of device time); at
+    // c = 16 (557 K buckets) four lanes per segment would oversubscribe the SIMDs and lose.
+    const bool four = ReduceCfg<F>::kFourLane || pl.NB <= kFourLaneMaxBuckets;
+    const uint32_t seg_per_block = four ? 64u : 256u;
+    if (four) pl.S = std::max(1u, (pl.NB + 64u * 232u - 1u) / (64u * 232u));
     else pl.S = std::max(2u, (pl.NB + 256u * 140u - 1u) / (256u * 140u));   // ~140 working blocks (0.5 wave/SIMD):
                                                                             // measured optimum, more waves contend on stack traffic
     const uint32_t seg_per_win = (std::max(pl.B, pl.BT) + pl.S - 1) / pl.S;
@@ -733,7 +737,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     else
         hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
-    if (ReduceCfg<F>::kFourLane)
+    if (four)
         hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
     else
         hipLaunchKernelGGL(k_msm_reduce1<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
