@@ -458,9 +458,10 @@ __device__ __forceinline__ Fp2 grp_mul_line(const Fp2 &f, const LineRec &l, int 
     return add(add(t0, w2 ? t2x : t2), w3 ? t3x : t3);
 }
 // product of the 8 groups of a wave, left in group 0
-template <int CALLER> __device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, int gbase) {
+// (only the first `live` groups hold something other than one: levels whose partners are all one are skipped)
+template <int CALLER> __device__ __forceinline__ void wave_group_product(Fp2 &acc, int lane, int sub, int gbase, int live = 8) {
     const int gi = lane >> 3;
-    for (int step = 1; step < 8; step <<= 1) {
+    for (int step = 1; step < 8 && step < live; step <<= 1) {
         Fp2 partner = shfl_from(acc, (lane + 8 * step) & 63);
         if ((gi & (2 * step - 1)) == 0) acc = grp_mul_dense<CALLER>(acc, partner, sub, gbase);
     }
@@ -491,7 +492,16 @@ k_pair_tree(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__ pmont
             acc = grp_mul_line(acc, l, sub, gbase);
         }
     }
-    wave_group_product<0>(acc, lane, sub, gbase);
+    // groups of this block / wave that hold lines (small batches leave most of them at one: their
+    // tree levels are skipped -- 5 dense products less at k <= 8, the whole chain of a 2-pair check)
+    const uint32_t ngroups = (k + group_lines - 1) / group_lines;
+    const int live_blk = (int)min(32u, ngroups - min(ngroups, blockIdx.x * 32u));
+    const int live_wave = max(0, min(8, live_blk - 8 * wave));
+    wave_group_product<0>(acc, lane, sub, gbase, live_wave);
+    if (live_blk <= 8) {                       // uniform in the block: wave 0 alone holds the product
+        if (wave == 0 && lane < 6) blk_out[((size_t)s * gridDim.x + blockIdx.x) * 6 + tower_slot(lane)] = acc;
+        return;
+    }
     if (lane < 6) sm[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && lane < 16) {
@@ -499,7 +509,7 @@ k_pair_tree(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__ pmont
         const int gq = lane >> 3, sidx = sub < 6 ? sub : 0;
         acc = grp_mul_dense<0>(sm[2 * gq][sidx], sm[2 * gq + 1][sidx], sub, gbase);
         const Fp2 partner = shfl_from(acc, 8 + sub);
-        if (gq == 0) acc = grp_mul_dense<0>(acc, partner, sub, 0);
+        if (gq == 0 && live_blk > 16) acc = grp_mul_dense<0>(acc, partner, sub, 0);
         if (lane < 6) blk_out[((size_t)s * gridDim.x + blockIdx.x) * 6 + tower_slot(lane)] = acc;
     }
 }
@@ -519,7 +529,7 @@ k_pair_tree2(const Fp2 *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ s
         Fp2 partner = blk_out[((size_t)s * nblk + b) * 6 + tower_slot(sub < 6 ? sub : 0)];
         acc = grp_mul_dense<1>(acc, partner, sub, gbase);
     }
-    wave_group_product<1>(acc, lane, sub, gbase);
+    wave_group_product<1>(acc, lane, sub, gbase, (int)min(8u, nblk));
     if (lane < 6) step_out[(size_t)s * 6 + tower_slot(lane)] = acc;
 }
 
@@ -566,8 +576,10 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
     else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k, blk_out, group_lines);
-    hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
+    // one block per step (k <= 32 group_lines): its output IS L_s, same [step][6] layout as step_out
+    hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k,
+                       tree_blocks == 1 ? step_out : blk_out, group_lines);
+    if (tree_blocks > 1) hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(64), 0, s, blk_out, tree_blocks, step_out);
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
