@@ -15,7 +15,7 @@
 //                           product per lane, or one Fp product per lane for batches <= 2048); store the
 //                           68 sparse lines (a0, a1 xP, a4 yP); the walk ends at T = [|z|]Q,
 //                           which IS the G2 membership test psi(Q) == -[|z|]Q
-//   k_pair_check_g1 [pair]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
+//   k_pair_check_g1 [pair = 4 lanes]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
 //   k_pair_tree    [a run of lines of one step per 8-lane group]  each Fp12 is spread over a lane
 //                           group (one Fp2 coefficient per lane); sparse line products, then a
 //                           per-wave product tree over shuffles and an LDS step across waves
@@ -50,21 +50,75 @@ static constexpr int kSteps = 68;        // 63 doublings + 5 additions for |z| =
 
 struct LineRec { Fp2 a0, a1, a4; };      // l = a0 + a1 v + a4 v w   (a1, a4 already scaled by xP, yP)
 
+// ---- G1 membership, 4 lanes per pair ----------------------------------------------------------
+// phi(P) == -[z^2]P is two 64-bit double-and-add chains (126 doublings, 10 additions).  One lane per
+// pair made that 1.5-1.8 ms of serial products -- the critical path of every batch below ~2000 pairs
+// once the line walk got shorter.  Here a pair owns 4 lanes: the independent Fp products of an
+// XYZZ doubling (3 rounds) or addition (4 rounds) go one per lane and are exchanged by shuffles.
+__device__ __forceinline__ Fp g1mul(const Fp &a, const Fp &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_mul_cols28(a, b);
+#else
+    return mul(a, b);
+#endif
+}
+// P + Q (add-2008-s), operands replicated on the 4 lanes of the group, complete
+__device__ __forceinline__ Xyzz<Fp> g1_add4(const Xyzz<Fp> &p, const Xyzz<Fp> &q, int r, int gb) {
+    if (is_inf(q)) return p;                                  // uniform in the group
+    if (is_inf(p)) return q;
+    Fp pr = g1mul(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
+    const Fp U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
+    const Fp Pd = sub(U2, U1), Rr = sub(S2, S1);
+    if (is_zero(Pd)) {                                        // same x: double or cancel (small-order inputs)
+        if (is_zero(Rr)) return dbl(p);
+        return xyzz_inf<Fp>();
+    }
+    pr = g1mul(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
+    const Fp PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
+    pr = g1mul(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
+    const Fp PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
+    const Fp X3 = sub(sub(RR, PPP), dbl(Q));
+    pr = g1mul(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
+    const Fp t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    return Xyzz<Fp>{X3, sub(t0, t1), ZZ3, ZZZ3};
+}
+// 2P (dbl-2008-s-1); infinity stays infinity (zz = 0 propagates)
+__device__ __forceinline__ Xyzz<Fp> g1_dbl4(const Xyzz<Fp> &p, int r, int gb) {
+    const Fp U = dbl(p.y);
+    Fp pr = g1mul(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
+    const Fp V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
+    const Fp M = add(dbl(XX), XX);
+    pr = g1mul(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
+    const Fp W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
+    const Fp X3 = sub(MM, dbl(S));
+    pr = g1mul(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
+    const Fp t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    return Xyzz<Fp>{X3, sub(t0, t1), ZZ3, ZZZ3};
+}
+// [|z|]p on the 4 lanes of the group
+__device__ __forceinline__ Xyzz<Fp> g1_mul_zabs4(const Xyzz<Fp> &p, int r, int gb) {
+    const uint64_t z = K_Z_ABS;
+    Xyzz<Fp> acc = p;
+    for (int i = 62; i >= 0; i--) {
+        acc = g1_dbl4(acc, r, gb);
+        if ((z >> i) & 1ull) acc = g1_add4(acc, p, r, gb);
+    }
+    return acc;
+}
 __global__ void __launch_bounds__(64)
 k_pair_check_g1(const uint32_t *__restrict__ in, uint32_t k, unsigned long long *err) {
-    uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= k) return;
+    const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
+    const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
+    if (i >= k) return;                                       // uniform in the group
     Aff<Fp> p;
     int st = decode_point<Fp>(p, in + (size_t)i * kPairWords);
     if (st == E_SUCCESS && !is_inf(p)) {
-        // phi(P) == -[z^2]P  (curve.h in_g1), on the inlined-product field type: this kernel is a
-        // 136-step serial chain per lane, so call overhead is pure latency
-        Aff<FpI> q{FpI{p.x}, FpI{p.y}};
-        Xyzz<FpI> t = mul_zabs(mul_zabs(q));
-        Aff<FpI> phi_neg{mul(q.x, FpI{Fp{{K_BETA}}}), neg(q.y)};
+        // phi(P) == -[z^2]P  (curve.h in_g1)
+        const Xyzz<Fp> t = g1_mul_zabs4(g1_mul_zabs4(from_affine(p), r, gb), r, gb);
+        Aff<Fp> phi_neg{mul(p.x, Fp{{K_BETA}}), neg(p.y)};
         if (!eq_affine(t, phi_neg)) st = E_NOT_IN_SUBGROUP;
     }
-    if (st != E_SUCCESS) atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)st);
+    if (st != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)st);
 }
 
 // ---- line walk, 4 lanes per pair --------------------------------------------------------------
@@ -539,13 +593,12 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
         fprintf(stderr, "[eip2537_hip] device input must be 4-byte aligned\n");
         return E_MEMORY_ERROR;
     }
-    const uint32_t blocks = (uint32_t)((k + 63) / 64);
     // 16 lanes per pair shorten the serial chain (small batches: 16 pairs 3.1 -> 2.7 ms) but replicate
     // the linear steps 4x more and put a wave on every SIMD at 2^12 pairs (3.4 vs 2.0 ms): by size
     const bool wide = k <= 2048;
-    // 8 lanes per pair while walk + G1 membership waves still find a SIMD each (k/8 + k/64 <= ~1000)
+    // 8 lanes per pair while walk + G1 membership waves still find a SIMD each (k/8 + k/16 <= ~1000)
     static const int env_l8 = [] { const char *v = getenv("EIP2537_LINES8"); return v ? atoi(v) : 1; }();
-    const bool mid = !wide && k <= 7168 && env_l8;
+    const bool mid = !wide && k <= 5120 && env_l8;
     const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : mid ? (uint32_t)((k + 7) / 8) : (uint32_t)((k + 15) / 16);
     // lines folded serially per 8-lane group: as few as possible while the whole grid (blocks x 68
     // steps) still fits in ONE round of 2 blocks per CU (512 slots); one block more than that and
@@ -569,7 +622,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     HIPCHK(hipEventRecord(e->ev_start, s));
     // fork: the G1 membership kernel runs beside the line walk
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_start, 0));
-    hipLaunchKernelGGL(k_pair_check_g1, dim3(blocks), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
+    hipLaunchKernelGGL(k_pair_check_g1, dim3((uint32_t)((k + 15) / 16)), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
     if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);

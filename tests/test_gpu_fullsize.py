@@ -146,10 +146,10 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
 
 
 def test_pairing_all_walk_kernels_ragged_sizes(X, clib):
-    """k <= 2048 runs the 16-lane line walk, k <= 7168 the 8-lane one, larger batches the 4-lane one;
+    """k <= 2048 runs the 16-lane line walk, k <= 5120 the 8-lane one, larger batches the 4-lane one;
     ragged sizes around both switches, each closed to the identity and broken by one, and an error
     in the last (partial) group."""
-    for k in (2047, 2049, 2100, 7167, 7169, 7203):
+    for k in (2047, 2049, 2100, 5119, 5121, 5203):
         good, bad = _pairing_batch(X, k, 0), _pairing_batch(X, k, 1)
         assert call_x(X.pairing, good) == (0, bytes(31) + b"\x01"), k
         assert call_x(X.pairing, bad) == (0, bytes(32)), k

@@ -197,3 +197,20 @@ def test_forced_window_width_without_a_valid_plan_falls_back(X, clib):
             assert call_x(X.g1_multiexp, inp) == want, c
     finally:
         X.set_window(0)
+
+
+def test_pairing_small_order_g1_points(X, clib):
+    """The G1 membership chain [z^2]P meets P, -P and infinity on the way when P has small order
+    (the complete-addition branches of the 4-lane kernel): (0, 2) has order 3."""
+    p3 = m.encode_g1((0, 2))
+    g2 = m.encode_g2(m.G2)
+    good = m.encode_g1(m.G1) + g2
+    for inp in (p3 + g2, good + p3 + g2, p3 + g2 + good, good * 5 + p3 + g2 + good * 3):
+        want = clib.call("bls12_pairing", inp)
+        assert want == (2, None)
+        assert call_x(X.pairing, inp) == want
+    # (0, -2) as well, and an order-3 point beside the point at infinity
+    n3 = m.encode_g1((0, m.P - 2))
+    assert call_x(X.pairing, n3 + g2) == clib.call("bls12_pairing", n3 + g2) == (2, None)
+    inp = bytes(128) + g2 + p3 + g2
+    assert call_x(X.pairing, inp) == clib.call("bls12_pairing", inp) == (2, None)
