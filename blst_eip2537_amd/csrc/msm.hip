@@ -634,6 +634,7 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, const Aff<Fp2> *pt
     hipLaunchKernelGGL(k_msm_accum2, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
+static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; };
 template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; };
 
@@ -646,11 +647,19 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     MsmPlan pl = msm_make_plan((uint32_t)n, c_override, ReduceCfg<F>::kFourLane);
     if (pl.max_entries >= (1ull << 32)) return E_MEMORY_ERROR;
-    // task length limit L = 2^lshift: at least 64, and at least twice the mean bucket load so that
-    // split buckets stay the exception (they cost an extra fold pass)
-    uint32_t lshift = 6;
+    // task length limit L = 2^lshift: at least twice the mean bucket load so that split buckets stay
+    // the exception (they cost an extra fold pass), and at least kMinTaskShift.  Below ~2^18 records
+    // the accumulate is not throughput-bound: its time is the longest task's chain (~12 us per mixed
+    // addition), set by the few heavy buckets of the short top window (c = 13: 512 buckets holding
+    // n/512 records each), so a shorter L there trades a few fold additions for a 2-4x shorter chain.
+    // (measured, min 64 -> 16: G1 2^14 1.20 -> 0.86 ms, 2^16 1.44 -> 1.15 ms, G2 2^16 3.25 -> 2.80 ms of
+    // device time; L below twice the mean load is far worse -- the fold pass then sees most buckets)
+    // (only for the c <= 13 plans, whose short top window is the chain in question; at c = 16 the
+    // floor of 64 changes nothing for ordinary inputs and keeps one-bucket adversarial inputs at
+    // 2.7 instead of 3.8 ms for 2^18 records)
+    uint32_t lshift = pl.c <= 13 ? kMinTaskShift : 6u;
     while (lshift < 20 && (1ull << lshift) < 2ull * n / pl.B) lshift++;
-    const uint32_t gshift = lshift - 6;           // granularity of the 64 task-length classes
+    const uint32_t gshift = lshift > 6 ? lshift - 6 : 0;   // granularity of the 64 task-length classes
     pl.L = 1u << lshift;
     pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
     // reduce: a latency-bound serial chain of ~2S + 30 point operations per segment.
