@@ -33,6 +33,12 @@ __device__ __forceinline__ FpI sel4(int r, const FpI &a, const FpI &b, const FpI
 __device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
     return Fp2{sel4(r, a.c0, b.c0, c.c0, d.c0), sel4(r, a.c1, b.c1, c.c1, d.c1)};
 }
+__device__ __forceinline__ Fp sel2(int r, const Fp &a, const Fp &b) {
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : b.l[i];
+    return o;
+}
 __device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
     Fp2 o;
 #pragma unroll

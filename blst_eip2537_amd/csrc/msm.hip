@@ -341,6 +341,8 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
 template <int HOT, class T> __device__ __forceinline__ T hmul(const T &a, const T &b) { return mul(a, b); }
 #if defined(__HIP_DEVICE_COMPILE__)
 template <> __device__ __forceinline__ Fp2 hmul<1, Fp2>(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
+template <> __device__ __forceinline__ Fp hmul<2, Fp>(const Fp &a, const Fp &b) { return fp_mul_cols28(a, b); }
+template <> __device__ __forceinline__ Fp2 hmul<2, Fp2>(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
 #endif
 
 // ---- G2 accumulate, 2 lanes per task ----------------------------------------------------------
@@ -349,39 +351,42 @@ template <> __device__ __forceinline__ Fp2 hmul<1, Fp2>(const Fp2 &a, const Fp2 
 // lanes: the ten products of madd-2008-s are dealt two per round in five rounds
 //   [U2 S2] [PP RR] [PPP Q] [ZZ3 Y1*PPP] [R*(Q-X3) ZZZ3]
 // (every lane busy in every round), halving the chain and doubling the waves.
-__device__ __forceinline__ Xyzz<Fp2> madd2(const Xyzz<Fp2> &p, const Aff<Fp2> &q, int r, int gb) {
+template <class T> __device__ __forceinline__ Xyzz<T> madd2(const Xyzz<T> &p, const Aff<T> &q, int r, int gb) {
     if (is_inf(q)) return p;                                   // uniform in the pair of lanes
-    if (is_inf(p)) return Xyzz<Fp2>{q.x, q.y, fp2_one(), fp2_one()};
-    Fp2 pr = hmul<EIP_G2_HOT_ACC>(sel2(r, q.x, q.y), sel2(r, p.zz, p.zzz));
-    const Fp2 U2 = shfl_from(pr, gb), S2 = shfl_from(pr, gb + 1);
-    const Fp2 Pd = sub(U2, p.x), Rr = sub(S2, p.y);
+    if (is_inf(p)) return Xyzz<T>{q.x, q.y, f_one<T>(), f_one<T>()};
+    T pr = hmul<2>(sel2(r, q.x, q.y), sel2(r, p.zz, p.zzz));
+    const T U2 = shfl_from(pr, gb), S2 = shfl_from(pr, gb + 1);
+    const T Pd = sub(U2, p.x), Rr = sub(S2, p.y);
     if (is_zero(Pd)) {
         if (is_zero(Rr)) return dbl_affine(q);
-        return xyzz_inf<Fp2>();
+        return xyzz_inf<T>();
     }
-    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
-    const Fp2 PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1);
-    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, Pd, p.x), PP);
-    const Fp2 PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1);
-    const Fp2 X3 = sub(sub(RR, PPP), dbl(Q));
-    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, p.zz, p.y), sel2(r, PP, PPP));
-    const Fp2 ZZ3 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1);
-    pr = hmul<EIP_G2_HOT_ACC>(sel2(r, Rr, p.zzz), sel2(r, sub(Q, X3), PPP));
-    const Fp2 t0 = shfl_from(pr, gb), ZZZ3 = shfl_from(pr, gb + 1);
-    return Xyzz<Fp2>{X3, sub(t0, t1), ZZ3, ZZZ3};
+    pr = hmul<2>(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
+    const T PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1);
+    pr = hmul<2>(sel2(r, Pd, p.x), PP);
+    const T PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1);
+    const T X3 = sub(sub(RR, PPP), dbl(Q));
+    pr = hmul<2>(sel2(r, p.zz, p.y), sel2(r, PP, PPP));
+    const T ZZ3 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1);
+    pr = hmul<2>(sel2(r, Rr, p.zzz), sel2(r, sub(Q, X3), PPP));
+    const T t0 = shfl_from(pr, gb), ZZZ3 = shfl_from(pr, gb + 1);
+    return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
+// G2 always; G1 for the plans whose accumulate is a chain rather than a stream (c <= 13, up to 2^17
+// records: the longest task, not the product rate, sets its time)
+template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_accum2(const Aff<Fp2> *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
-             const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp2> *__restrict__ partial) {
+k_msm_accum2(const Aff<F> *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
+             const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<F> *__restrict__ partial) {
     const int lane = threadIdx.x & 63, r = lane & 1, gb = lane & ~1;
     const uint32_t slot = blockIdx.x * 128u + (threadIdx.x >> 1);
     if (slot >= totals[1]) return;                             // uniform in the pair
     const uint32_t t = perm[slot];
     Task tk = tasks[t];
-    Xyzz<Fp2> acc = xyzz_inf<Fp2>();
+    Xyzz<F> acc = xyzz_inf<F>();
     for (uint32_t e = 0; e < tk.len; e++) {
         uint32_t ent = entries[tk.start + e];
-        Aff<Fp2> p = pts[ent >> 1];
+        Aff<F> p = pts[ent >> 1];
         if (ent & 1u) p.y = neg(p.y);
         acc = madd2(acc, p, r, gb);
     }
@@ -625,13 +630,16 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     }
 }
 
-static void launch_accum(hipStream_t s, uint32_t task_blocks, const Aff<Fp> *pts, const uint32_t *entries, const Task *tasks,
-                         const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
-    hipLaunchKernelGGL(k_msm_accum<Fp>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const uint32_t *entries,
+                         const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
+    if (chain_bound)
+        hipLaunchKernelGGL(k_msm_accum2<Fp>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    else
+        hipLaunchKernelGGL(k_msm_accum<Fp>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
-static void launch_accum(hipStream_t s, uint32_t task_blocks, const Aff<Fp2> *pts, const uint32_t *entries, const Task *tasks,
-                         const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
-    hipLaunchKernelGGL(k_msm_accum2, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp2> *pts, const uint32_t *entries,
+                         const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
+    hipLaunchKernelGGL(k_msm_accum2<Fp2>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
@@ -739,7 +747,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    launch_accum(s, task_blocks, pts, entries, tasks, perm, totals, partial);
+    // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
+    launch_accum(s, task_blocks, pl.c <= 13, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
     if (ReduceCfg<F>::kFourLane)
         hipLaunchKernelGGL(k_msm_fold_small4<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
