@@ -324,25 +324,25 @@ __device__ __forceinline__ Prod4 fp2_products8(const Fp2 &u, const Fp2 &v, int q
     o.r3 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
     return o;
 }
-// same result as miller_dbl_step (pairing.h)
-__device__ __forceinline__ Line miller_dbl_step8(MillerT &T, int p, int q, int gbase) {
+// same result as miller_dbl_step (pairing.h); the line coefficients are stored as soon as they exist
+// (a0 after the second round) so that their operands do not stay live through the third
+__device__ __forceinline__ void miller_dbl_step8(MillerT &T, int p, int q, int gbase, LineRec *dst, bool contributes, int sl) {
     Prod4 pr = fp2_products8(sel4(p, T.x, T.y, T.z, T.y), sel4(p, T.x, T.y, T.z, T.z), q, gbase);
     const Fp2 A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
     const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
     pr = fp2_products8(sel4(p, B, XB, E, E), sel4(p, B, XB, E, T.x), q, gbase);
     const Fp2 C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
+    if (sl == 0) dst->a0 = contributes ? sub(EX, dbl(B)) : fp2_one();          // 3X^3 - 2Y^2
     const Fp2 D = dbl(sub(sub(t, A), C));
     const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
+    const Fp2 C8 = dbl(dbl(dbl(C)));
     pr = fp2_products8(sel4(p, E, Z3, E, E), sel4(p, ZZ, ZZ, sub(D, X3), ZZ), q, gbase);
     const Fp2 EZ = pr.r0, Z3ZZ = pr.r1, Ym = pr.r2;
-    Line l;
-    l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
-    l.a1 = neg(EZ);                   // -3X^2 Z^2
-    l.a4 = Z3ZZ;                      // 2YZ^3
+    if (sl == 1) dst->a1 = contributes ? neg(EZ) : fp2_zero();                 // -3X^2 Z^2
+    if (sl == 2) dst->a4 = contributes ? Z3ZZ : fp2_zero();                    // 2YZ^3
     T.x = X3;
-    T.y = sub(Ym, dbl(dbl(dbl(C))));
+    T.y = sub(Ym, C8);
     T.z = Z3;
-    return l;
 }
 
 __global__ void __launch_bounds__(64)
@@ -377,12 +377,11 @@ k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__
     const uint64_t z = K_Z_ABS;
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
-        Line l = miller_dbl_step8(T, pidx, q, gbase);
-        store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
+        miller_dbl_step8(T, pidx, q, gbase, &lines[(size_t)s * k + i], contributes, sl);
         s++;
         if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
             Aff<Fp2> Q = sQ[gi];
-            l = miller_add_step(T, Q);
+            Line l = miller_add_step(T, Q);
             store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
             s++;
         }
