@@ -757,7 +757,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
     launch_accum(s, task_blocks, pl.c <= 13, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    if (ReduceCfg<F>::kFourLane)
+    if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
         hipLaunchKernelGGL(k_msm_fold_small4<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
     else
         hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
