@@ -4,23 +4,35 @@
 One "step" = one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: by default one bls12_g1multiexp over 2^20 (point, scalar) records
 (BASELINE.json metric "G1 MSM pairs/sec at 2^20"), called through the C-ABI
-(eip2537_hip_g1multiexp_dev).  With N > 1 ranks (torch.distributed / RCCL, one process per GPU)
-ONE larger MSM is sharded by contiguous record range, 2^20 records per GPU (weak scaling: the
-metric's size per GPU): every rank reduces its shard to one 192-byte partial point, the partials
-are all-gathered over RCCL and combined into the precompile's output.  `--scaling strong` instead
-shards one 2^20-record MSM over the N GPUs (BASELINE config 5 literally; at 2^17 records per
-GPU the ~2 ms of fixed latency dominates -- see profiles/r01_size_sweep.txt).
+(eip2537_hip_g1multiexp_dev).
+
+`--gpus N` with N > 1 runs N ranks, one process per GPU (torch.distributed, backend nccl = RCCL).
+Launched by torchrun / torch.distributed.run the ranks are already there (WORLD_SIZE is set);
+launched as plain `python bench.py --gpus N` this process starts them itself -- before it imports
+torch or touches HIP -- and exits with their status.  ONE larger MSM is sharded by contiguous
+record range, 2^20 records per GPU (weak scaling: the metric's size per GPU): every rank reduces
+its shard to one 192-byte partial point, the partials are all-gathered over RCCL and combined into
+the precompile's output.  `--scaling strong` instead shards one 2^20-record MSM over the N GPUs
+(BASELINE config 5 literally; at 2^17 records per GPU the fixed chain latency dominates).
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
-  roofline      dominant kernel (k_msm_accum) against the HBM roof, from HIP events recorded on
-                the engine's own stream around that kernel (eip2537_hip_last_timing)
-  cpu_baseline  the CPU oracle's restatement of the reference path (Bos-Coster, 1 thread) timed
-                on a bounded sample of the same records, on this box's host cores
-  secondary     the second half of BASELINE's metric: one 2^12-pair bls12_pairing check
+  roofline       dominant kernel (named by the library: eip2537_hip_last_plan) against the HBM roof,
+                 from HIP events recorded on the engine's own stream around that kernel
+  roofline_valu  the same kernel against the v_mad_u64_u32 issue roof it actually lives under
+  host_abi       the reference-ABI call itself, bls12_g1multiexp on a host buffer (H2D included:
+                 SURVEY.md 8d's definition of the metric; never `value`)
+  cpu_baseline   the CPU oracle's restatement of the reference path (Bos-Coster, 1 thread) on the
+                 same records, on this box's host cores; cpu_all_cores: a bucket-method MSM on all
+                 host cores, for context, NOT the reference's algorithm
+  secondary      the second half of BASELINE's metric: one 2^12-pair bls12_pairing check
+  in_library_split  (N > 1) bls12_g1multiexp on a host buffer, cut over the N devices inside the library
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,6 +44,8 @@ A = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6
 B = 0x0123456789abcdef0fedcba987654321
 R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MAD_PEAK = 29441.6e9           # v_mad_u64_u32 lane-ops/s, chip-wide, measured (profiles/r01_valu_probe.txt)
+MADS_PER_FP_PRODUCT = 392      # 14 x 14 product + 14 x 14 reduction columns of 28-bit limbs (csrc/field.h)
 REC = {"g1msm": 160, "g2msm": 288, "pairing": 384}          # algorithmic bytes per unit
 FULL = {"g1msm": "eip2537_hip_g1multiexp_dev", "g2msm": "eip2537_hip_g2multiexp_dev",
         "pairing": "eip2537_hip_pairing_dev"}
@@ -40,16 +54,7 @@ PART = {"g1msm": "eip2537_hip_g1msm_partial_dev", "g2msm": "eip2537_hip_g2msm_pa
 COMB = {"g1msm": "eip2537_hip_g1msm_combine", "g2msm": "eip2537_hip_g2msm_combine",
         "pairing": "eip2537_hip_pairing_combine"}
 ORACLE = {"g1msm": "bls12_g1multiexp", "g2msm": "bls12_g2multiexp", "pairing": "bls12_pairing"}
-KERNEL = {"g1msm": "k_msm_accum<Fp>", "g2msm": "k_msm_accum2<Fp2>", "pairing": "k_pair_lines4"}
-
-
-def dominant_kernel(wl, n_local):
-    """Name of the kernel the library times as 'dominant' for this size (csrc/msm.hip, csrc/pairing.hip)."""
-    if wl == "g1msm":
-        return "k_msm_accum2<Fp>" if n_local <= (1 << 17) else "k_msm_accum<Fp>"      # c <= 13 plans: two-lane accumulate
-    if wl == "pairing":
-        return "k_pair_lines16" if n_local <= 2048 else "k_pair_lines8" if n_local <= 5120 else "k_pair_lines4"
-    return KERNEL[wl]
+HOSTFN = {"g1msm": "g1_multiexp", "g2msm": "g2_multiexp", "pairing": "pairing"}
 
 
 def seed_for(workload, log2n):
@@ -82,6 +87,88 @@ def golden(workload, log2n):
     return None
 
 
+def stats_ms(samples):
+    return {"mean": sum(samples) / len(samples), "median": statistics.median(samples), "min": min(samples),
+            "max": max(samples), "n": len(samples)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv, env=None, script=None):
+    """Start n copies of this script, one rank each, and return the worst exit status.  Called before
+    anything in this process has imported torch or initialised HIP, and the children are started as
+    child processes (never exec'd over a process that holds the GPU)."""
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base["WORLD_SIZE"] = str(n)
+    base["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=e))
+    worst = 0
+    deadline = time.time() + float(os.environ.get("BENCH_SPAWN_TIMEOUT", "1500"))
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+        if worst or time.time() > deadline:
+            for r in pending:                    # a rank failed (or the run hung): stop exactly our children
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            return worst or 124
+        time.sleep(0.05)
+    return worst
+
+
+def host_abi_leg(X, wl, host, n, reps):
+    """The reference-ABI call on a host buffer: H2D + decode + compute + encode."""
+    fn = getattr(X, HOSTFN[wl])
+    out = fn(host)                                # warm-up (grows the staging buffer)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn(host)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    st = stats_ms(ts)
+    return out, {"call": "bls12_%s (host buffer, %d bytes: H2D + decode + compute + encode)" % (ORACLE[wl][6:], len(host)),
+                 "ms_per_call": st, "value": n / (st["median"] * 1e-3), "value_best": n / (st["min"] * 1e-3),
+                 "unit": "pairs/s", "devices": X.device_count(), "plan": X.last_plan()}
+
+
+def split_child(args):
+    """`--split-child D`: a fresh process (no torch, no RCCL) that lets the LIBRARY cut one host-input
+    bls12_g1multiexp / bls12_pairing over the devices in $EIP2537_HIP_DEVICES and prints one JSON object."""
+    import blst_eip2537_amd as pkg
+    X = pkg.Eip2537Executor
+    wl = args.workload
+    log2n = args.log2n if args.log2n is not None else {"g1msm": 20, "g2msm": 16, "pairing": 12}[wl]
+    n = 1 << log2n
+    host = make_records(X, wl, n, 0, log2n)
+    if wl == "pairing":
+        host = pairing_fixup(X, host, n)
+    out, leg = host_abi_leg(X, wl, host, n, max(3, args.steps))
+    gold = bytes(31) + b"\x01" if wl == "pairing" else golden(wl, log2n)
+    leg["bit_exact_vs_golden"] = None if gold is None else (out == gold)
+    leg["EIP2537_HIP_DEVICES"] = os.environ.get("EIP2537_HIP_DEVICES")
+    print(json.dumps(leg), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,32 +180,53 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="force the Pippenger window width (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-host-abi", action="store_true")
+    ap.add_argument("--split-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.split_child:
+        return split_child(args)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (nothing here has touched HIP yet)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a wrong n_gpus\n" % (args.gpus, world))
+        sys.exit(2)
 
     import torch
     import blst_eip2537_amd as pkg
     X = pkg.Eip2537Executor
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the multiexp / pairing path has no CPU fallback")
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a GPU to rehearse the
     # sharded path on a 1-GPU box (everything but RCCL itself)
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(1, ndev)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank "
+                         "(BENCH_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
+    dev_index = local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dist = None
+    cpu_group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            cpu_group = dist.new_group(backend="gloo")      # host-side waits that must not spin on the GPUs
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    X.init(dev_index)
+        assert dist.get_world_size() == args.gpus
+    X.init(dev_index)                     # one process per GPU: pin the library to this rank's device
     if args.window:
         X.set_window(args.window)
 
@@ -144,9 +252,10 @@ def main():
     if world > 1:
         gather_buf = torch.empty(world * psz, dtype=torch.uint8, device="cuda")
 
-    kernel_ms, pipe_ms = [], []
+    kernel_ms, pipe_ms, step_ms = [], [], []
 
     def step():
+        t0 = time.perf_counter()
         if world == 1:
             out = X.dev_call(FULL[wl], d_in.data_ptr(), n_local)
         else:
@@ -160,6 +269,7 @@ def main():
                 dist.all_gather(parts, mine)
                 allp = b"".join(bytes(t.numpy().tobytes()) for t in parts)
             out = X.combine(COMB[wl], [allp[i * psz:(i + 1) * psz] for i in range(world)])
+        step_ms.append((time.perf_counter() - t0) * 1e3)
         p, k = X.last_timing()
         pipe_ms.append(p)
         kernel_ms.append(k)
@@ -175,6 +285,7 @@ def main():
         out = step()
     kernel_ms.clear()
     pipe_ms.clear()
+    step_ms.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -185,6 +296,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    plan = X.last_plan() or {}
 
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
     value = n_total / (ms_per_step * 1e-3)
@@ -197,25 +309,29 @@ def main():
 
     # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
     # same command (counters cannot be read from inside the process); the summary is committed
-    # under profiles/ and only quoted when it was taken on the workload being run.
+    # under profiles/ and only quoted when it was taken on the workload and kernel being run.
     traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
+    for tname in ("r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath):
+            continue
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("workload") == wl and tj.get("log2n") == log2n and world == 1:
+        if tj.get("workload") == wl and tj.get("log2n") == log2n and world == 1 and \
+                tj.get("kernel", plan.get("kernel")) == plan.get("kernel"):
             traffic = tj["traffic_bytes_raw"]
             traffic_note = ("PMC (FETCH_SIZE+WRITE_SIZE)*1024 per launch, raw; %.3g with the gfx950 x2 FETCH correction "
-                            "(calibrated for coalesced streams only; this kernel gathers 96-B points, 16 window passes "
-                            "over a 101 MB point array that stays in the 256 MB Infinity Cache). VALU issue: %.3f "
-                            "wave-instructions per SIMD-cycle. Source: profiles/r01_pmc_g1msm_2p20.csv"
-                            % (tj["traffic_bytes_fetch_x2"], tj["valu_wave_instr_per_simd_cycle"]))
+                            "(calibrated for coalesced streams only; this kernel gathers 96-B points, one pass per window "
+                            "over a 101 MB point array that stays in the 256 MB Infinity Cache). Source: profiles/%s"
+                            % (tj["traffic_bytes_fetch_x2"], tj.get("source", tname)))
+        break
 
     result = None
     if rank == 0:
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         p_ms = sum(pipe_ms) / max(1, len(pipe_ms))
         achieved = REC[wl] * n_local / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        st = stats_ms(step_ms)
         result = {
             "metric": {"g1msm": "g1_msm_pairs_per_sec", "g2msm": "g2_msm_pairs_per_sec",
                        "pairing": "pairing_pairs_per_sec"}[wl],
@@ -225,40 +341,48 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s over 2^%d records total (%d per GPU), input resident in HBM, via C-ABI %s"
                                    % (ORACLE[wl], log2_total, n_local, FULL[wl] if world == 1 else PART[wl] + " + RCCL all_gather + combine"),
-                       "records_total": n_total, "records_per_gpu": n_local,
+                       "records_total": n_total, "records_per_gpu": n_local, "world_size": world,
                        "parallelism": "1 GPU" if world == 1 else "record-range shards x%d, RCCL all_gather of %d-byte partials" % (world, psz)},
+            "step_ms": st,                                     # rank 0's own clock around every step
+            "value_median": n_total / (st["median"] * 1e-3), "value_best": n_total / (st["min"] * 1e-3),
             "bit_exact_vs_golden": parity,
             # the reference Go bench's own unit (go/blst_eip2537_test.go:126-130), gas of the whole input
             "mgas_per_s": X.gas({"g1msm": "g1multiexp", "g2msm": "g2multiexp", "pairing": "pairing"}[wl],
                                 n_total * REC[wl]) / (ms_per_step * 1e-3) / 1e6,
-            "roofline": {"bound": "hbm", "kernel": dominant_kernel(wl, n_local), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "plan": plan,
+            "roofline": {"bound": "hbm", "kernel": plan.get("kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": k_ms, "device_pipeline_ms": p_ms,
                          "algorithmic_bytes_per_unit": REC[wl], "units_per_launch": n_local,
                          "note": "integer-VALU-bound by construction (SURVEY.md 8d): the HBM fraction is reported because the metric asks for it"},
         }
-        # the roof this path actually lives under: Fp products per second of the dominant kernel against
-        # the bare product-chain rate of the same v_mad_u64_u32 code (profiles/r01_fpmul_bench.txt)
-        if wl in ("g1msm", "g2msm") and k_ms > 0:
-            c_plan = {20: 16, 16: 13}.get(log2n)
-            windows = None if c_plan is None else (256 + c_plan - 1) // c_plan
-            if windows is not None and 256 - (windows - 1) * c_plan < 8:
-                windows -= 1
-            if windows is not None:
-                prods = n_local * windows * (10 if wl == "g1msm" else 30)      # 8M+2S per mixed addition; Fp2 = 3 Fp
-                result["roofline_valu"] = {"bound": "valu (v_mad_u64_u32 issue)", "kernel": dominant_kernel(wl, n_local),
-                                           "achieved": prods / (k_ms * 1e-3) / 1e9, "peak": 64.7, "unit": "G Fp-products/s",
-                                           "frac": prods / (k_ms * 1e-3) / 1e9 / 64.7,
-                                           "note": "algorithmic products = records x windows x 10 (x3 over Fp2); peak = measured chip-wide rate of the shipped product in isolation (profiles/r01_fpmul_bench.txt, V2)"}
+        # the roof this path actually lives under: multiply-adds issued per second by the dominant
+        # kernel against the measured chip-wide v_mad_u64_u32 issue rate
+        if wl in ("g1msm", "g2msm") and k_ms > 0 and plan.get("windows"):
+            prods = n_local * plan["windows"] * (10 if wl == "g1msm" else 30)      # 8M+2S per mixed addition; Fp2 = 3 Fp
+            mads = prods * MADS_PER_FP_PRODUCT
+            result["roofline_valu"] = {
+                "bound": "valu (v_mad_u64_u32 issue)", "kernel": plan.get("kernel"),
+                "achieved": mads / (k_ms * 1e-3) / 1e12, "peak": MAD_PEAK / 1e12, "unit": "T mad lane-ops/s",
+                "frac": mads / (k_ms * 1e-3) / MAD_PEAK, "fp_products_per_launch": prods,
+                "note": "algorithmic Fp products = records x windows (%d, c = %d) x 10 (x3 over Fp2), %d multiply-adds each; "
+                        "peak = chip-wide v_mad_u64_u32 rate measured by tools/valu_probe.hip (profiles/r01_valu_probe.txt)"
+                        % (plan["windows"], plan.get("window_bits", 0), MADS_PER_FP_PRODUCT)}
 
-    # ---- CPU baseline: oracle restatement of the reference path, 1 thread, bounded sample
+    # ---- the reference-ABI call itself: host buffer in, H2D inside the timed call
+    if rank == 0 and world == 1 and not args.no_host_abi:
+        hout, leg = host_abi_leg(X, wl, host, n_local, 3)
+        leg["matches_device_resident_result"] = hout == out
+        result["host_abi"] = leg
+
+    # ---- CPU baseline: oracle restatement of the reference path, 1 thread, on the same records
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import clib
         if wl == "pairing":
             sample_n = min(n_local, 2048)
             sample = pairing_fixup(X, host[:sample_n * 384], sample_n) if sample_n < n_local else host
         else:
-            sample_n = min(n_local, 1 << 18 if wl == "g1msm" else 1 << 16)
+            sample_n = min(n_local, 1 << 20 if wl == "g1msm" else 1 << 16)
             sample = host[:sample_n * REC[wl]]
         t1 = time.perf_counter()
         rc, cpu_out = clib.call(ORACLE[wl], sample)
@@ -271,10 +395,20 @@ def main():
             ok = ok and X.dev_call(FULL[wl], d_s.data_ptr(), sample_n) == cpu_out
         result["cpu_baseline"] = {
             "value": sample_n / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "first 2^%d records of the same workload, oracle %s (reference control flow: Bos-Coster / sequential Miller loops), %.1f s; host has %d cores"
-                      % (sample_n.bit_length() - 1, ORACLE[wl], dt, os.cpu_count() or 0),
+            "sample": "%s 2^%d records of the same workload, oracle %s (reference control flow: Bos-Coster / sequential Miller loops), one run of %.1f s; host has %d cores"
+                      % ("all" if sample_n == n_local else "first", sample_n.bit_length() - 1, ORACLE[wl], dt, os.cpu_count() or 0),
             "gpu_matches_cpu_on_sample": bool(ok),
         }
+        if wl == "g1msm":
+            cores = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            rc, mt_out = clib.g1_pippenger_mt(sample, cores)
+            dt = time.perf_counter() - t1
+            result["cpu_all_cores"] = {
+                "value": sample_n / dt, "unit": "pairs/s", "cores": cores, "kind": "NOT the reference's algorithm",
+                "sample": "same 2^%d records, bucket-method MSM of the oracle on %d pthreads (windows dealt over threads), %.2f s: "
+                          "context only -- the reference is single-threaded Bos-Coster (README.md:15-17)" % (sample_n.bit_length() - 1, cores, dt),
+                "matches": rc == 0 and mt_out == cpu_out}
 
     # ---- secondary: the pairing half of the BASELINE metric (one 2^12-pair check)
     if rank == 0 and world == 1 and wl == "g1msm" and not args.no_secondary:
@@ -283,19 +417,26 @@ def main():
         d_p = torch.frombuffer(bytearray(ph), dtype=torch.uint8).cuda()
         pout = X.dev_call(FULL["pairing"], d_p.data_ptr(), k)
         torch.cuda.synchronize()
-        reps, kms = 3, []
-        t1 = time.perf_counter()
+        reps, kms, pms, tms = 5, [], [], []
         for _ in range(reps):
+            t1 = time.perf_counter()
             pout = X.dev_call(FULL["pairing"], d_p.data_ptr(), k)
+            tms.append((time.perf_counter() - t1) * 1e3)
+            pms.append(X.last_timing()[0])
             kms.append(X.last_timing()[1])
-        torch.cuda.synchronize()
-        dtp = (time.perf_counter() - t1) / reps
-        sec = {"metric": "pairing_pairs_per_sec", "value": k / dtp, "unit": "pairs/s", "ms_per_check": dtp * 1e3,
+        pst = stats_ms(tms)
+        pplan = X.last_plan() or {}
+        sec = {"metric": "pairing_pairs_per_sec", "value": k / (pst["mean"] * 1e-3), "unit": "pairs/s", "ms_per_check": pst,
+               "value_median": k / (pst["median"] * 1e-3), "value_best": k / (pst["min"] * 1e-3),
                "pairs": k, "result_is_one": pout == bytes(31) + b"\x01",
-               "mgas_per_s": X.gas("pairing", k * 384) / dtp / 1e6,
-               "roofline": {"bound": "hbm", "kernel": dominant_kernel("pairing", k), "achieved": 384 * k / (sum(kms) / reps * 1e-3) / 1e9,
+               "mgas_per_s": X.gas("pairing", k * 384) / (pst["mean"] * 1e-3) / 1e6,
+               "roofline": {"bound": "hbm", "kernel": pplan.get("kernel"), "achieved": 384 * k / (sum(kms) / reps * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 384 * k / (sum(kms) / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "kernel_ms": sum(kms) / reps}}
+                            "traffic": None, "kernel_ms": sum(kms) / reps, "device_pipeline_ms": sum(pms) / reps}}
+        if not args.no_host_abi:
+            hout, leg = host_abi_leg(X, "pairing", ph, k, 3)
+            leg["result_is_one"] = hout == bytes(31) + b"\x01"
+            sec["host_abi"] = leg
         if not args.no_cpu_baseline:
             from oracle import clib
             sk = 1024
@@ -308,10 +449,27 @@ def main():
                                    "result_is_one": rc == 0 and cout == bytes(31) + b"\x01"}
         result["secondary"] = sec
 
+    # ---- N > 1: the same total input through the reference ABI of ONE process, cut over the N
+    # devices inside the library (thread per device, host combine).  Runs in a fresh child of rank 0
+    # while the other ranks wait on the host (gloo), their GPUs idle.
+    if world > 1 and wl in ("g1msm", "pairing") and not args.no_host_abi:
+        if rank == 0:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+            env["EIP2537_HIP_DEVICES"] = ",".join(str(r % max(1, ndev)) for r in range(world))
+            cmd = [sys.executable, os.path.abspath(__file__), "--split-child", "--workload", wl, "--steps", str(args.steps),
+                   "--log2n", str(log2n if args.scaling == "strong" else min(log2_total, 23))]
+            try:
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                result["in_library_split"] = json.loads(line[-1]) if cp.returncode == 0 and line else {"error": (cp.stderr or cp.stdout)[-400:]}
+            except Exception as ex:                          # the headline number must survive this leg
+                result["in_library_split"] = {"error": repr(ex)}
+        dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -16,6 +16,9 @@
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <thread>
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
@@ -43,30 +46,81 @@ void DevBuf::release() {
     cap = 0;
 }
 
-// Engine slots.  The ABI has no handle to hang state on and its callers are concurrent (cargo's
-// test threads, goroutines: SURVEY.md 8b "Threading"), so the library keeps a small pool of
-// engines -- each with its own streams, events and grow-only workspace -- and a call borrows one
-// for its duration.  Calls on different slots overlap on the GPU (small inputs fill a fraction of
-// the 256 CUs); when every slot is busy a caller waits for the next release.
+// Engine pools.  The ABI has no handle to hang state on and its callers are concurrent (cargo's
+// test threads, goroutines: SURVEY.md 8b "Threading"), so the library keeps, per HIP device, a
+// small pool of engines -- each with its own streams, events and grow-only workspace -- and a call
+// borrows one for its duration.  Calls on different slots overlap on the GPU (small inputs fill a
+// fraction of the 256 CUs); when every slot of a pool is busy a caller waits for the next release.
+//
+// Devices.  `g_split` lists the pools a HOST-input call may use: $EIP2537_HIP_DEVICES ("all" or a
+// comma list of ordinals; an ordinal may repeat, which gives it a second pool -- used by the tests to
+// run the multi-device split on one GPU), else the single device of eip2537_hip_init(d) /
+// $EIP2537_HIP_DEVICE, else every visible device.  Large host inputs are cut into contiguous record
+// ranges, one per listed device and host thread (each device copies its range over its own PCIe
+// link); small ones go to the least busy pool.  Device-input calls (`*_dev`) run on the device that
+// owns the pointer.
 static constexpr int kMaxSlots = 16;
-static std::mutex g_mu;                 // guards the slot table and one-time device selection
+static constexpr int kMaxPools = 32;
+struct DevicePool {
+    int ordinal = -1;
+    Engine slots[kMaxSlots];
+    bool busy[kMaxSlots] = {};
+    int nbusy = 0;
+};
+static std::mutex g_mu;                 // guards the pool tables and one-time device selection
 static std::condition_variable g_cv;
-static Engine g_slots[kMaxSlots];
-static bool g_busy[kMaxSlots];
-static int g_nslots = 0;                // 0 = device not selected yet
-static int g_device = 0;
+static DevicePool g_pools[kMaxPools];
+static int g_npools = 0;
+static int g_split[kMaxPools];          // pool indices host-input calls are spread over
+static int g_nsplit = 0;                // 0 = devices not selected yet
+static int g_nslots = 8;
+static int g_ndev = 0;
 static int g_device_request = -1;
+static size_t g_keep_bytes = (size_t)4096 << 20;     // per-slot workspace kept between calls
 static std::atomic<int> g_window_override{0};
-static thread_local float t_last_kernel_ms = 0.f, t_last_accum_ms = 0.f;
-static float g_last_kernel_ms = 0.f, g_last_accum_ms = 0.f;
+static std::atomic<int> g_route_override{-1};        // -1 default, 0 always GPU, 1 always host (small-call tests)
 
+struct CallStats {
+    float pipeline_ms = 0.f, dominant_ms = 0.f;
+    LastPlan plan{};
+    bool valid = false;
+};
+static thread_local CallStats t_last;
+static CallStats g_last;
+
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told
+// otherwise) and streams sharing a queue run one after the other; every slot drives up to three
+// streams.  The variable is read when the runtime initialises, so it is set (never overriding the
+// embedder's own value) when this library is loaded -- before its first HIP call, and for a linked
+// binary before main() starts any thread -- instead of from inside a precompile call.
+__attribute__((constructor)) static void eip_library_loaded() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+// Make `dev` current on this thread for the duration of a call and put the caller's device back
+// afterwards (an embedder such as torch keeps its own notion of the current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+static int pool_new_locked(int ordinal) {
+    if (g_npools >= kMaxPools) return -1;
+    g_pools[g_npools].ordinal = ordinal;
+    return g_npools++;
+}
+static int pool_for_ordinal_locked(int ordinal) {
+    for (int i = 0; i < g_npools; i++)
+        if (g_pools[i].ordinal == ordinal) return i;
+    return pool_new_locked(ordinal);
+}
 static bool device_select_locked() {
-    if (g_nslots) return true;
-    // Each slot drives up to three streams; the HIP runtime multiplexes a process's streams onto
-    // GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise) and streams sharing a queue run
-    // one after the other.  Ask for more before the runtime starts, unless the embedder chose a
-    // value (no effect, and no harm, when HIP was already initialised by the host program).
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    if (g_nsplit) return true;
     int ndev = 0;
     hipError_t er = hipGetDeviceCount(&ndev);
     if (er != hipSuccess || ndev == 0) {
@@ -74,78 +128,153 @@ static bool device_select_locked() {
                         "path has no CPU fallback\n", er == hipSuccess ? "0 devices" : hipGetErrorString(er));
         return false;
     }
-    int dev = g_device_request;
-    if (dev < 0) {
-        const char *env = getenv("EIP2537_HIP_DEVICE");
-        dev = env ? atoi(env) : 0;
+    g_ndev = ndev;
+    int want[kMaxPools], nwant = 0;
+    const char *list = getenv("EIP2537_HIP_DEVICES");
+    if (g_device_request >= 0) {
+        want[nwant++] = g_device_request;
+    } else if (list && *list && strcmp(list, "all") != 0) {
+        for (const char *c = list; *c && nwant < kMaxPools;) {
+            char *endp = nullptr;
+            long v = strtol(c, &endp, 10);
+            if (endp == c) { fprintf(stderr, "[eip2537_hip] FATAL: cannot parse EIP2537_HIP_DEVICES=\"%s\"\n", list); return false; }
+            want[nwant++] = (int)v;
+            c = *endp == ',' ? endp + 1 : endp;
+            if (*endp && *endp != ',') { fprintf(stderr, "[eip2537_hip] FATAL: cannot parse EIP2537_HIP_DEVICES=\"%s\"\n", list); return false; }
+        }
+    } else if (const char *one = (list ? nullptr : getenv("EIP2537_HIP_DEVICE"))) {
+        want[nwant++] = atoi(one);
+    } else {
+        for (int d = 0; d < ndev && nwant < kMaxPools; d++) want[nwant++] = d;
     }
-    if (dev >= ndev) dev = dev % ndev;
-    if (hipSetDevice(dev) != hipSuccess) { fprintf(stderr, "[eip2537_hip] FATAL: hipSetDevice(%d) failed\n", dev); return false; }
-    g_device = dev;
+    for (int i = 0; i < nwant; i++)
+        if (want[i] < 0 || want[i] >= ndev) {
+            fprintf(stderr, "[eip2537_hip] FATAL: HIP device ordinal %d requested, %d device(s) visible\n", want[i], ndev);
+            return false;
+        }
     const char *env = getenv("EIP2537_HIP_SLOTS");
     int ns = env ? atoi(env) : 8;
     g_nslots = ns < 1 ? 1 : ns > kMaxSlots ? kMaxSlots : ns;
-    return true;
+    if ((env = getenv("EIP2537_HIP_KEEP_MB"))) g_keep_bytes = (size_t)strtoull(env, nullptr, 10) << 20;
+    int ns_out = 0;
+    for (int i = 0; i < nwant; i++) {
+        bool repeat = false;
+        for (int j = 0; j < i; j++) repeat |= want[j] == want[i];
+        int pi = repeat ? pool_new_locked(want[i]) : pool_for_ordinal_locked(want[i]);
+        if (pi < 0) return false;
+        g_split[ns_out++] = pi;
+    }
+    g_nsplit = ns_out;
+    return g_nsplit > 0;
 }
-static bool slot_init(Engine &e) {
+static bool slot_init(Engine &e, int ordinal) {
     if (e.ready) return true;
-    e.device = g_device;
+    e.device = ordinal;
     bool ok = hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e.stream3, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&e.ev_start) == hipSuccess && hipEventCreate(&e.ev_stop) == hipSuccess &&
               hipEventCreate(&e.ev_a) == hipSuccess && hipEventCreate(&e.ev_b) == hipSuccess &&
               hipEventCreate(&e.ev_j2) == hipSuccess && hipEventCreate(&e.ev_j3) == hipSuccess;
-    if (!ok) { fprintf(stderr, "[eip2537_hip] FATAL: stream/event creation failed\n"); return false; }
+    if (!ok) { fprintf(stderr, "[eip2537_hip] FATAL: stream/event creation failed on device %d\n", ordinal); return false; }
     e.ready = true;
+    e.failed = false;
     return true;
 }
-// Borrow an engine for one call (RAII).  `e` is null when no device is usable.
+// After a HIP failure in the middle of a pipeline: wait for whatever is still in flight on any of
+// the slot's streams (a forked kernel may still be writing the error word), then drop the streams,
+// events and workspace so that the next borrower starts from a freshly created engine.
+static void slot_reset(Engine &e) {
+    if (e.stream) (void)hipStreamSynchronize(e.stream);
+    if (e.stream2) (void)hipStreamSynchronize(e.stream2);
+    if (e.stream3) (void)hipStreamSynchronize(e.stream3);
+    (void)hipGetLastError();
+    for (hipStream_t *s : {&e.stream, &e.stream2, &e.stream3}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
+    for (hipEvent_t *v : {&e.ev_start, &e.ev_stop, &e.ev_a, &e.ev_b, &e.ev_j2, &e.ev_j3}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
+    e.release_workspace();
+    e.ready = false;
+    e.failed = false;
+}
+// Borrow an engine of pool `pi` for one call (RAII).  `e` is null when no device is usable.
 struct SlotLease {
     Engine *e = nullptr;
-    int idx = -1;
-    SlotLease() {
+    int pi = -1, idx = -1;
+    DeviceGuard *guard = nullptr;
+    explicit SlotLease(int pool_index) {
         std::unique_lock<std::mutex> lk(g_mu);
         if (!device_select_locked()) return;
+        if (pool_index < 0) {                      // any listed device: the least busy pool
+            pool_index = g_split[0];
+            for (int i = 1; i < g_nsplit; i++)
+                if (g_pools[g_split[i]].nbusy < g_pools[pool_index].nbusy) pool_index = g_split[i];
+        }
+        pi = pool_index;
+        DevicePool &p = g_pools[pi];
         for (;;) {
             for (int i = 0; i < g_nslots; i++)
-                if (!g_busy[i]) { idx = i; break; }
+                if (!p.busy[i]) { idx = i; break; }
             if (idx >= 0) break;
             g_cv.wait(lk);
         }
-        g_busy[idx] = true;
+        p.busy[idx] = true;
+        p.nbusy++;
         lk.unlock();
         // the slot is ours now: create its streams outside the table lock
-        if (hipSetDevice(g_device) == hipSuccess && slot_init(g_slots[idx])) { e = &g_slots[idx]; return; }
+        guard = new DeviceGuard(p.ordinal);
+        if (guard->ok && slot_init(p.slots[idx], p.ordinal)) { e = &p.slots[idx]; return; }
+        delete guard;
+        guard = nullptr;
         lk.lock();
-        g_busy[idx] = false;
+        p.busy[idx] = false;
+        p.nbusy--;
         idx = -1;
-        g_cv.notify_one();
+        g_cv.notify_all();
     }
     ~SlotLease() {
         if (idx < 0) return;
-        t_last_kernel_ms = e->last_kernel_ms;
-        t_last_accum_ms = e->last_accum_ms;
+        t_last.pipeline_ms = e->last_kernel_ms;
+        t_last.dominant_ms = e->last_accum_ms;
+        t_last.plan = e->last_plan;
+        t_last.valid = true;
+        if (e->failed) slot_reset(*e);
+        else if (e->workspace_bytes() > g_keep_bytes) e->release_workspace();
+        delete guard;
         std::lock_guard<std::mutex> lk(g_mu);
-        g_last_kernel_ms = t_last_kernel_ms;
-        g_last_accum_ms = t_last_accum_ms;
-        g_busy[idx] = false;
-        g_cv.notify_one();
+        g_last = t_last;
+        g_pools[pi].busy[idx] = false;
+        g_pools[pi].nbusy--;
+        g_cv.notify_all();
     }
     SlotLease(const SlotLease &) = delete;
     SlotLease &operator=(const SlotLease &) = delete;
 };
+// pool of the device that owns a device pointer (for the *_dev entry points); -1 = not device memory
+static int pool_of_pointer(const void *d_ptr) {
+    hipPointerAttribute_t at;
+    int ordinal = -1;
+    if (hipPointerGetAttributes(&at, d_ptr) == hipSuccess && at.type == hipMemoryTypeDevice) ordinal = at.device;
+    else (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!device_select_locked()) return -1;
+    if (ordinal < 0) return -2;
+    // a single-device process (one rank per GPU) keeps using its own pool
+    for (int i = 0; i < g_nsplit; i++)
+        if (g_pools[g_split[i]].ordinal == ordinal) return g_split[i];
+    return pool_for_ordinal_locked(ordinal);
+}
 
-// Host -> device staging of the caller's buffer.  The copy is complete before this returns, so
-// the caller's pointer is never retained (Go / Rust own the memory: SURVEY.md 8b "Ownership").
+// Host -> device staging of the caller's buffer on the engine's own stream: the kernels that read it
+// are ordered behind the copy by the stream, and the call does not return before its last kernel has
+// finished, so the caller's pointer is never retained (Go / Rust own the memory: SURVEY.md 8b).
 static int stage_input(Engine *e, const void *in, size_t len) {
     if (e->input.reserve(len) != hipSuccess) {
         fprintf(stderr, "[eip2537_hip] hipMalloc of %zu staging bytes failed\n", len);
+        e->failed = true;
         return E_MEMORY_ERROR;
     }
-    if (hipSetDevice(e->device) != hipSuccess) return E_MEMORY_ERROR;
-    if (hipMemcpy(e->input.p, in, len, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpyAsync(e->input.p, in, len, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
         fprintf(stderr, "[eip2537_hip] host-to-device copy failed\n");
+        e->failed = true;
         return E_MEMORY_ERROR;
     }
     return E_SUCCESS;
@@ -190,10 +319,11 @@ template <class F> static int msm_dispatch(Engine *e, const void *d_in, size_t n
 template <> int msm_dispatch<Fp>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g1_device(e, d_in, n, pw, g_window_override.load()); }
 template <> int msm_dispatch<Fp2>(Engine *e, const void *d_in, size_t n, uint32_t *pw) { return msm_g2_device(e, d_in, n, pw, g_window_override.load()); }
 
-// mode: 0 = host input (stage it), 1 = device input; want_partial: write the XYZZ partial
+// One device pipeline on pool `pi` (-1: least busy listed device).  device_input: `in` is already in
+// HBM on that pool's device; want_partial: write the projective partial instead of the encoding.
 template <class F>
-static int msm_entry(byte *out, const void *in, size_t n, bool device_input, bool want_partial) {
-    SlotLease lease;
+static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_input, bool want_partial) {
+    SlotLease lease(pi);
     Engine *e = lease.e;
     if (!e) return E_MEMORY_ERROR;
     const void *d_in = in;
@@ -212,10 +342,78 @@ static int msm_entry(byte *out, const void *in, size_t n, bool device_input, boo
     }
     return E_SUCCESS;
 }
+template <class F> static int msm_dev_abi(byte *out, const void *d_in, size_t n, bool want_partial) {
+    if (!n) return E_INVALID_LENGTH;
+    int pi = pool_of_pointer(d_in);
+    if (pi == -2) { fprintf(stderr, "[eip2537_hip] %p is not device memory\n", d_in); return E_MEMORY_ERROR; }
+    if (pi < 0) return E_MEMORY_ERROR;
+    return msm_entry<F>(pi, out, d_in, n, true, want_partial);
+}
+
+// ---- record-range split over the listed devices -------------------------------------
+// A host-input call with at least two shards' worth of records is cut into contiguous ranges, one per
+// listed device; each range is staged and reduced by its own host thread on its own device (its own
+// PCIe link), down to one projective partial (MSM) or one Fp12 Miller product (pairing); the caller's
+// thread runs shard 0 and combines.  Point addition / Fp12 multiplication of N partials on the host is
+// what replaces a collective inside one process (no RCCL: there is no second process to talk to).
+// Errors: shards are ordered record ranges, so the lowest-index bad record of the whole input is the
+// one reported by the first failing shard.
+// Minimum records per shard, from the single-GPU size sweep (profiles/r01_size_sweep.txt: below these
+// sizes a call costs its fixed chain latency whatever its size, so cutting it further buys nothing).
+template <class F> struct SplitMin { static constexpr size_t kRecords = (size_t)1 << 16; };
+template <> struct SplitMin<Fp2> { static constexpr size_t kRecords = (size_t)1 << 15; };
+static constexpr size_t kPairingSplitMin = 1024;
+static size_t split_min_override() {
+    static const size_t v = [] { const char *e = getenv("EIP2537_HIP_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }();
+    return v;
+}
+// pools to use for n units: empty => one pipeline on the least busy device
+static std::vector<int> split_plan(size_t n, size_t min_per_shard) {
+    std::vector<int> pools;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!device_select_locked()) return pools;
+        if (split_min_override()) min_per_shard = split_min_override();
+        size_t shards = std::min<size_t>((size_t)g_nsplit, n / std::max<size_t>(1, min_per_shard));
+        if (shards < 2) return pools;
+        pools.assign(g_split, g_split + shards);
+    }
+    return pools;
+}
+// run fn(shard) for every shard, shard 0 on the calling thread
+template <class Fn> static void run_shards(size_t shards, Fn &&fn) {
+    std::vector<std::thread> th;
+    std::vector<CallStats> stats(shards);
+    for (size_t s = 1; s < shards; s++) th.emplace_back([&, s] { fn(s); stats[s] = t_last; });
+    fn(0);
+    stats[0] = t_last;
+    for (auto &t : th) t.join();
+    // the call's timing is that of its slowest shard
+    for (size_t s = 1; s < shards; s++)
+        if (stats[s].valid && stats[s].pipeline_ms > t_last.pipeline_ms) t_last = stats[s];
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_last = t_last;
+}
+
 template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_len) {
     const size_t rec = Wire<F>::kMsmRecWords * 4;
     if (in_len == 0 || in_len % rec) return E_INVALID_LENGTH;      // before touching `in`
-    return msm_entry<F>(out, in, in_len / rec, false, false);
+    const size_t n = in_len / rec;
+    const std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
+    if (pools.empty()) return msm_entry<F>(-1, out, in, n, false, false);
+    const size_t shards = pools.size();
+    std::vector<Xyzz<F>> parts(shards);
+    std::vector<int> rc(shards, E_MEMORY_ERROR);
+    run_shards(shards, [&](size_t s) {
+        const size_t lo = n * s / shards, hi = n * (s + 1) / shards;
+        rc[s] = msm_entry<F>(pools[s], reinterpret_cast<byte *>(&parts[s]), in + lo * rec, hi - lo, false, true);
+    });
+    for (size_t s = 0; s < shards; s++)
+        if (rc[s]) return rc[s];
+    Xyzz<F> acc = parts[0];
+    for (size_t s = 1; s < shards; s++) acc = add(acc, parts[s]);
+    host_encode_point<F>(out, to_affine(acc));
+    return E_SUCCESS;
 }
 template <class F> static int msm_combine(byte *out, const uint8_t *partials, size_t count) {
     Xyzz<F> acc = xyzz_inf<F>();
@@ -233,8 +431,8 @@ static void pairing_finish(byte *out, const Fp12 &ml) {
     memset(out, 0, 32);
     if (one) out[31] = 1;
 }
-static int pairing_entry(byte *out, const void *in, size_t k, bool device_input, bool want_partial) {
-    SlotLease lease;
+static int pairing_entry(int pi, byte *out, const void *in, size_t k, bool device_input, bool want_partial) {
+    SlotLease lease(pi);
     Engine *e = lease.e;
     if (!e) return E_MEMORY_ERROR;
     const void *d_in = in;
@@ -247,6 +445,32 @@ static int pairing_entry(byte *out, const void *in, size_t k, bool device_input,
     int st = pairing_device(e, d_in, k, reinterpret_cast<uint32_t *>(&ml));
     if (st) return st;
     if (want_partial) memcpy(out, &ml, sizeof ml); else pairing_finish(out, ml);
+    return E_SUCCESS;
+}
+static int pairing_dev_abi(byte *out, const void *d_in, size_t k, bool want_partial) {
+    if (!k) return E_INVALID_LENGTH;
+    int pi = pool_of_pointer(d_in);
+    if (pi == -2) { fprintf(stderr, "[eip2537_hip] %p is not device memory\n", d_in); return E_MEMORY_ERROR; }
+    if (pi < 0) return E_MEMORY_ERROR;
+    return pairing_entry(pi, out, d_in, k, true, want_partial);
+}
+static int pairing_host_abi(byte *out, const byte *in, size_t in_len) {
+    if (in_len == 0 || in_len % 384) return E_INVALID_LENGTH;       // before touching `in`
+    const size_t k = in_len / 384;
+    const std::vector<int> pools = split_plan(k, kPairingSplitMin);
+    if (pools.empty()) return pairing_entry(-1, out, in, k, false, false);
+    const size_t shards = pools.size();
+    std::vector<Fp12> parts(shards);
+    std::vector<int> rc(shards, E_MEMORY_ERROR);
+    run_shards(shards, [&](size_t s) {
+        const size_t lo = k * s / shards, hi = k * (s + 1) / shards;
+        rc[s] = pairing_entry(pools[s], reinterpret_cast<byte *>(&parts[s]), in + lo * 384, hi - lo, false, true);
+    });
+    for (size_t s = 0; s < shards; s++)
+        if (rc[s]) return rc[s];
+    Fp12 acc = parts[0];
+    for (size_t s = 1; s < shards; s++) acc = mul(acc, parts[s]);
+    pairing_finish(out, acc);
     return E_SUCCESS;
 }
 
@@ -334,10 +558,7 @@ API EIP2537_ERROR bls12_g2multiexp(byte out[256], byte *in, size_t in_len) { ret
 API EIP2537_ERROR bls12_g2multiexp_naive(byte out[256], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp2>(out, in, in_len); }
 API EIP2537_ERROR bls12_g2multiexp_bc(byte out[256], byte *in, size_t in_len) { return (EIP2537_ERROR)msm_host_abi<Fp2>(out, in, in_len); }
 
-API EIP2537_ERROR bls12_pairing(byte out[32], byte *in, size_t in_len) {
-    if (in_len == 0 || in_len % 384) return EIP2537_INVALID_LENGTH;
-    return (EIP2537_ERROR)pairing_entry(out, in, in_len / 384, false, false);
-}
+API EIP2537_ERROR bls12_pairing(byte out[32], byte *in, size_t in_len) { return (EIP2537_ERROR)pairing_host_abi(out, in, in_len); }
 
 // map-to-curve: RFC 9380 map_to_curve of ONE field element, then cofactor clearing -- what the
 // reference gets from blst_map_to_g1/_g2(out, u, NULL) (:1113, :1155).  Host code (csrc/h2c.h).
@@ -406,16 +627,26 @@ API uint64_t bls12_map_fp2_to_g2_gas(void) { return BLS12_MAP_FP2_TO_G2_GAS; }
 // ------------------------------------------------------------------ extensions
 API int eip2537_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_nslots) return g_device == device || device < 0 ? 0 : E_MEMORY_ERROR;
+    if (g_nsplit) {           // already selected: fine if it is the same single device (or "whatever is selected")
+        if (device < 0 || (g_nsplit == 1 && g_pools[g_split[0]].ordinal == device)) return 0;
+        fprintf(stderr, "[eip2537_hip] eip2537_hip_init(%d): devices were already selected\n", device);
+        return E_MEMORY_ERROR;
+    }
     g_device_request = device;
-    return device_select_locked() ? 0 : E_MEMORY_ERROR;
+    bool ok = device_select_locked();
+    if (!ok) g_device_request = -1;
+    return ok ? 0 : E_MEMORY_ERROR;
 }
-API int eip2537_hip_g1multiexp_dev(uint8_t out[128], const void *d_in, size_t n) { return n ? msm_entry<Fp>(out, d_in, n, true, false) : E_INVALID_LENGTH; }
-API int eip2537_hip_g2multiexp_dev(uint8_t out[256], const void *d_in, size_t n) { return n ? msm_entry<Fp2>(out, d_in, n, true, false) : E_INVALID_LENGTH; }
-API int eip2537_hip_pairing_dev(uint8_t out[32], const void *d_in, size_t k) { return k ? pairing_entry(out, d_in, k, true, false) : E_INVALID_LENGTH; }
-API int eip2537_hip_g1msm_partial_dev(uint8_t *partial, const void *d_in, size_t n) { return n ? msm_entry<Fp>(partial, d_in, n, true, true) : E_INVALID_LENGTH; }
-API int eip2537_hip_g2msm_partial_dev(uint8_t *partial, const void *d_in, size_t n) { return n ? msm_entry<Fp2>(partial, d_in, n, true, true) : E_INVALID_LENGTH; }
-API int eip2537_hip_pairing_partial_dev(uint8_t *partial, const void *d_in, size_t k) { return k ? pairing_entry(partial, d_in, k, true, true) : E_INVALID_LENGTH; }
+API int eip2537_hip_device_count(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return device_select_locked() ? g_nsplit : 0;
+}
+API int eip2537_hip_g1multiexp_dev(uint8_t out[128], const void *d_in, size_t n) { return msm_dev_abi<Fp>(out, d_in, n, false); }
+API int eip2537_hip_g2multiexp_dev(uint8_t out[256], const void *d_in, size_t n) { return msm_dev_abi<Fp2>(out, d_in, n, false); }
+API int eip2537_hip_pairing_dev(uint8_t out[32], const void *d_in, size_t k) { return pairing_dev_abi(out, d_in, k, false); }
+API int eip2537_hip_g1msm_partial_dev(uint8_t *partial, const void *d_in, size_t n) { return msm_dev_abi<Fp>(partial, d_in, n, true); }
+API int eip2537_hip_g2msm_partial_dev(uint8_t *partial, const void *d_in, size_t n) { return msm_dev_abi<Fp2>(partial, d_in, n, true); }
+API int eip2537_hip_pairing_partial_dev(uint8_t *partial, const void *d_in, size_t k) { return pairing_dev_abi(partial, d_in, k, true); }
 API int eip2537_hip_g1msm_combine(uint8_t out[128], const uint8_t *partials, size_t count) { return msm_combine<Fp>(out, partials, count); }
 API int eip2537_hip_g2msm_combine(uint8_t out[256], const uint8_t *partials, size_t count) { return msm_combine<Fp2>(out, partials, count); }
 API int eip2537_hip_pairing_combine(uint8_t out[32], const uint8_t *partials, size_t count) {
@@ -431,9 +662,43 @@ API int eip2537_hip_pairing_combine(uint8_t out[32], const uint8_t *partials, si
 API void eip2537_hip_last_timing(float *pipeline_ms, float *dominant_kernel_ms) {
     // the calling thread's last call if it made one, else the process's last call
     std::lock_guard<std::mutex> lk(g_mu);
-    bool mine = t_last_kernel_ms != 0.f;
-    if (pipeline_ms) *pipeline_ms = mine ? t_last_kernel_ms : g_last_kernel_ms;
-    if (dominant_kernel_ms) *dominant_kernel_ms = mine ? t_last_accum_ms : g_last_accum_ms;
+    const CallStats &c = t_last.valid ? t_last : g_last;
+    if (pipeline_ms) *pipeline_ms = c.pipeline_ms;
+    if (dominant_kernel_ms) *dominant_kernel_ms = c.dominant_ms;
+}
+API int eip2537_hip_last_plan(char *kernel_name, size_t cap, int *window_bits, int *windows, int *lanes,
+                              uint32_t *units, uint32_t *buckets) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const CallStats &c = t_last.valid ? t_last : g_last;
+    if (!c.valid) return E_EMPTY_INPUT;
+    if (kernel_name && cap) { strncpy(kernel_name, c.plan.kernel, cap - 1); kernel_name[cap - 1] = 0; }
+    if (window_bits) *window_bits = c.plan.c;
+    if (windows) *windows = c.plan.windows;
+    if (lanes) *lanes = c.plan.lanes;
+    if (units) *units = c.plan.units;
+    if (buckets) *buckets = c.plan.buckets;
+    return 0;
+}
+// Release the workspace of every idle engine slot that holds more than keep_bytes (slots grow to the
+// largest call they have served: ~0.9 GB after one 2^20-record MSM).  Returns the bytes released.
+API size_t eip2537_hip_trim(size_t keep_bytes) {
+    size_t freed = 0;
+    std::unique_lock<std::mutex> lk(g_mu);
+    for (int p = 0; p < g_npools; p++)
+        for (int i = 0; i < kMaxSlots; i++) {
+            Engine &e = g_pools[p].slots[i];
+            if (g_pools[p].busy[i] || !e.ready) continue;
+            const size_t ws = e.workspace_bytes();
+            if (ws <= keep_bytes) continue;
+            g_pools[p].busy[i] = true;           // ours while the lock is dropped for the frees
+            lk.unlock();
+            { DeviceGuard g(g_pools[p].ordinal); e.release_workspace(); }
+            lk.lock();
+            g_pools[p].busy[i] = false;
+            freed += ws;
+        }
+    g_cv.notify_all();
+    return freed;
 }
 API int eip2537_hip_set_window(int c) {
     if (c != 0 && (c < 4 || c > 16)) return E_INVALID_LENGTH;

@@ -14,8 +14,21 @@ struct DevBuf {
     void release();
 };
 
+// What the last device pipeline on an engine actually ran (reported through
+// eip2537_hip_last_plan so that bench.py labels its roofline from the library, not from a copy of
+// the dispatch thresholds).
+struct LastPlan {
+    char kernel[48];   // dominant kernel, as rocprofv3 names it
+    int c;             // MSM window bits (0 for a pairing batch)
+    int windows;       // MSM windows (pairing: Miller steps)
+    int lanes;         // lanes per task / pair of the dominant kernel
+    uint32_t units;    // records / pairs of the launch
+    uint32_t buckets;  // MSM buckets (0 for a pairing batch)
+};
+
 struct Engine {
     bool ready = false;
+    bool failed = false;   // a HIP call failed mid-pipeline: the slot is drained and rebuilt on release
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr;
@@ -36,7 +49,15 @@ struct Engine {
     DevBuf winout;         // per (window, reduce block) sums (pairing: per-block / per-step Fp12 products)
     // last-call kernel timing (ms), filled when timing is enabled
     float last_kernel_ms = 0.f;   // whole device pipeline of the last call
-    float last_accum_ms = 0.f;    // dominant kernel of the last call (k_msm_accum / k_pair_miller)
+    float last_accum_ms = 0.f;    // dominant kernel of the last call (named in last_plan.kernel)
+    LastPlan last_plan{};
+
+    template <class Fn> void for_each_buf(Fn &&fn) {
+        for (DevBuf *b : {&input, &misc, &pts, &digits, &hist16, &slice_base, &counts, &offsets, &taskoff, &scan_blk,
+                          &entries, &tasks, &perm, &split_lists, &partial, &winout}) fn(*b);
+    }
+    size_t workspace_bytes() { size_t t = 0; for_each_buf([&](DevBuf &b) { t += b.cap; }); return t; }
+    void release_workspace() { for_each_buf([](DevBuf &b) { b.release(); }); }
 };
 
 // Window plan for one MSM

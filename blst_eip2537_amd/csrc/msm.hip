@@ -33,6 +33,7 @@ namespace eip {
         if (_e != hipSuccess) {                                                                 \
             fprintf(stderr, "[eip2537_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), \
                     __FILE__, __LINE__);                                                        \
+            e->failed = true;          /* the slot is drained and rebuilt when the lease ends */        \
             return E_MEMORY_ERROR;                                                              \
         }                                                                                       \
     } while (0)
@@ -650,8 +651,8 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp
 }
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
-template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; };
-template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; };
+template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; static constexpr const char *kName = "eip::Fp"; };
+template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; static constexpr const char *kName = "eip::Fp2"; };
 
 template <class F>
 static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
@@ -733,6 +734,13 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
 
+    {
+        const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
+        LastPlan lp{};
+        snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
+        lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB;
+        e->last_plan = lp;
+    }
     HIPCHK(hipEventRecord(e->ev_start, s));
     hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, digits, err);
     hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);

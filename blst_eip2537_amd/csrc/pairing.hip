@@ -41,6 +41,7 @@ namespace eip {
         if (_e != hipSuccess) {                                                                 \
             fprintf(stderr, "[eip2537_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), \
                     __FILE__, __LINE__);                                                        \
+            e->failed = true;          /* the slot is drained and rebuilt when the lease ends */        \
             return E_MEMORY_ERROR;                                                              \
         }                                                                                       \
     } while (0)
@@ -616,6 +617,12 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     auto *step_out = blk_out + (size_t)kSteps * tree_blocks * 6;           // [step] Fp12
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
 
+    {
+        LastPlan lp{};
+        snprintf(lp.kernel, sizeof lp.kernel, "%s", wide ? "k_pair_lines16" : mid ? "k_pair_lines8" : "k_pair_lines4");
+        lp.windows = kSteps; lp.lanes = wide ? 16 : mid ? 8 : 4; lp.units = (uint32_t)k;
+        e->last_plan = lp;
+    }
     hipStream_t s = e->stream;
     HIPCHK(hipMemsetAsync(err, 0xFF, 8, s));
     HIPCHK(hipEventRecord(e->ev_start, s));

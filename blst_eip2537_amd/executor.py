@@ -90,6 +90,13 @@ def lib():
     L.eip2537_hip_init.argtypes = [ctypes.c_int]
     L.eip2537_hip_set_window.restype = ctypes.c_int
     L.eip2537_hip_set_window.argtypes = [ctypes.c_int]
+    L.eip2537_hip_device_count.restype = ctypes.c_int
+    L.eip2537_hip_device_count.argtypes = []
+    L.eip2537_hip_trim.restype = ctypes.c_size_t
+    L.eip2537_hip_trim.argtypes = [ctypes.c_size_t]
+    L.eip2537_hip_last_plan.restype = ctypes.c_int
+    L.eip2537_hip_last_plan.argtypes = [ctypes.c_char_p, ctypes.c_size_t] + [ctypes.POINTER(ctypes.c_int)] * 3 + \
+                                       [ctypes.POINTER(ctypes.c_uint32)] * 2
     L.eip2537_hip_last_timing.restype = None
     L.eip2537_hip_last_timing.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     _lib = L
@@ -200,6 +207,26 @@ class Eip2537Executor:
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         lib().eip2537_hip_last_timing(ctypes.byref(a), ctypes.byref(b))
         return a.value, b.value
+
+    @staticmethod
+    def last_plan():
+        """What the last GPU call ran: dict(kernel, window_bits, windows, lanes, units, buckets) or None."""
+        name = ctypes.create_string_buffer(64)
+        c, w, ln = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        u, b = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        if lib().eip2537_hip_last_plan(name, 64, ctypes.byref(c), ctypes.byref(w), ctypes.byref(ln),
+                                       ctypes.byref(u), ctypes.byref(b)) != 0:
+            return None
+        return {"kernel": name.value.decode(), "window_bits": c.value, "windows": w.value, "lanes": ln.value,
+                "units": u.value, "buckets": b.value}
+
+    @staticmethod
+    def device_count():
+        return int(lib().eip2537_hip_device_count())
+
+    @staticmethod
+    def trim(keep_bytes=0):
+        return int(lib().eip2537_hip_trim(keep_bytes))
 
     @staticmethod
     def set_window(c):

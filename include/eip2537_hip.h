@@ -26,9 +26,20 @@ extern "C" {
 #define EIP2537_HIP_G2_PARTIAL_BYTES 384   /* XYZZ point over Fp2                   */
 #define EIP2537_HIP_ML_PARTIAL_BYTES 576   /* Fp12 Miller-loop product              */
 
-/* Select the HIP device for this process (default: device 0, or $EIP2537_HIP_DEVICE) and
- * initialise the engine.  Optional: every entry point initialises lazily. */
+/* Devices.  Optional: every entry point initialises lazily.
+ *   eip2537_hip_init(d), d >= 0   this process uses HIP device d only (one process per GPU: what
+ *                                 bench.py's ranks do).  An ordinal that is not visible is an error.
+ *   otherwise                     $EIP2537_HIP_DEVICES = "all" | comma list of ordinals, else
+ *                                 $EIP2537_HIP_DEVICE = one ordinal, else every visible device.
+ * With more than one device listed, the reference-ABI calls (bls12_g1multiexp / bls12_g2multiexp /
+ * bls12_pairing, host input) cut a large input into contiguous record ranges, one per device and
+ * host thread -- each device copies and reduces its own range -- and combine the partials on the
+ * host (reference src/eip2537.c:541-561 has one CPU loop in that place); small inputs go to the
+ * least busy device.  Returns 0, or EIP2537_MEMORY_ERROR when no such device exists or a different
+ * selection was already made.  The caller's current HIP device is preserved across every call. */
 int eip2537_hip_init(int device);
+/* Number of devices host-input calls are spread over (initialises the selection); 0 = no device. */
+int eip2537_hip_device_count(void);
 
 /* Full precompile on an input already resident in HBM. */
 int eip2537_hip_g1multiexp_dev(uint8_t out[128], const void *d_in, size_t n_records);
@@ -44,10 +55,21 @@ int eip2537_hip_g1msm_combine(uint8_t out[128], const uint8_t *partials, size_t 
 int eip2537_hip_g2msm_combine(uint8_t out[256], const uint8_t *partials, size_t count);
 int eip2537_hip_pairing_combine(uint8_t out[32], const uint8_t *partials, size_t count);
 
-/* Device time of the last GPU call made by this process, in milliseconds, from HIP events on
- * the engine's own stream: the whole device pipeline, and its dominant kernel (k_msm_accum for
- * an MSM, k_pair_miller for a pairing batch). */
+/* Device time of the last GPU call made by this thread (else by the process), in milliseconds,
+ * from HIP events on the engine's own stream: the whole device pipeline, and its dominant kernel
+ * (the bucket accumulate of an MSM, the line walk of a pairing batch -- named by
+ * eip2537_hip_last_plan).  For a call split over several devices: the slowest shard. */
 void eip2537_hip_last_timing(float *pipeline_ms, float *dominant_kernel_ms);
+/* What that call ran: the dominant kernel's name as rocprofv3 prints it, the Pippenger window width
+ * and window count (pairing: 0 and the 68 Miller steps), lanes per task / pair, the records / pairs
+ * of the launch and the bucket count.  Any pointer may be NULL.  Returns 0, or EIP2537_EMPTY_INPUT
+ * when no GPU call has been made yet. */
+int eip2537_hip_last_plan(char *kernel_name, size_t cap, int *window_bits, int *windows, int *lanes,
+                          uint32_t *units, uint32_t *buckets);
+/* Engine slots keep the workspace of the largest call they served (about 0.9 GB after one
+ * 2^20-record MSM; a slot above $EIP2537_HIP_KEEP_MB, default 4096, frees it when the call ends).
+ * This releases the workspace of every idle slot holding more than keep_bytes; returns the bytes freed. */
+size_t eip2537_hip_trim(size_t keep_bytes);
 
 /* Synthetic workloads (host code, for benchmarks and tests; not a precompile): records
  * i in [start, start+n) with P_i = [a + i*b]G and k_i = SplitMix64(seed) words 4i..4i+3;

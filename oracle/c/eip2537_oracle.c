@@ -440,6 +440,79 @@ EXPORT uint64_t oracle_pairing_gas(uint64_t len) {
     return k ? 115000 + 23000 * k : 0;
 }
 
+/* ------------------------------------------------------------------ context baseline: all-cores Pippenger
+ * NOT the reference's algorithm (the reference is single-threaded Bos-Coster, src/eip2537.c:619-708,
+ * README.md:15-17): a plain bucket method over unsigned c-bit windows, windows dealt over `threads`
+ * pthreads, so that bench.py can print "what the host's cores could do" next to the 1-thread port
+ * (SURVEY.md 8d).  Same input, same canonical output as oracle_bls12_g1multiexp. */
+#include <pthread.h>
+typedef struct {
+    const g1_aff *pts; const uint8_t *scal; size_t n, stride; int c, W, first, step; g1_jac *winsum;
+} ora_pip_job;
+static void *ora_pip_worker(void *arg) {
+    ora_pip_job *j = arg;
+    const size_t nb = ((size_t)1 << j->c) - 1;
+    g1_jac *bk = malloc(nb * sizeof *bk);
+    if (!bk) return (void *)1;
+    for (int w = j->first; w < j->W; w += j->step) {
+        for (size_t b = 0; b < nb; b++) g1_set_inf(&bk[b]);
+        const int lo = w * j->c;
+        for (size_t i = 0; i < j->n; i++) {
+            const uint8_t *k = j->scal + i * j->stride;          /* 32 bytes little-endian */
+            uint32_t d = 0;
+            for (int b = 0; b < j->c && lo + b < 256; b++) d |= (uint32_t)((k[(lo + b) >> 3] >> ((lo + b) & 7)) & 1) << b;
+            if (d && !g1_aff_is_inf(&j->pts[i])) g1_add_affine(&bk[d - 1], &bk[d - 1], &j->pts[i]);
+        }
+        g1_jac run, sum;
+        g1_set_inf(&run);
+        g1_set_inf(&sum);
+        for (size_t b = nb; b-- > 0;) { g1_add(&run, &run, &bk[b]); g1_add(&sum, &sum, &run); }
+        j->winsum[w] = sum;
+    }
+    free(bk);
+    return NULL;
+}
+EXPORT int oracle_g1_pippenger_mt(uint8_t *out, const uint8_t *in, size_t in_len, int threads) {
+    if (in_len == 0 || in_len % 160) return ORA_INVALID_LENGTH;
+    const size_t n = in_len / 160;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    int c = 4;
+    while (c < 16 && ((size_t)1 << (c + 4)) < n) c++;             /* ~n/16 buckets per window */
+    const int W = (256 + c - 1) / c;
+    g1_aff *pts = malloc(n * sizeof *pts);
+    uint8_t *scal = malloc(n * 32);
+    g1_jac *winsum = malloc((size_t)W * sizeof *winsum);
+    int rc = (pts && scal && winsum) ? ORA_SUCCESS : ORA_MEMORY_ERROR;
+    for (size_t i = 0; i < n && rc == ORA_SUCCESS; i++) {
+        rc = ora_decode_g1(&pts[i], in + i * 160);
+        ora_decode_scalar(scal + i * 32, in + i * 160 + 128);
+    }
+    if (rc == ORA_SUCCESS) {
+        pthread_t th[256];
+        ora_pip_job jobs[256];
+        for (int t = 0; t < threads; t++) {
+            jobs[t] = (ora_pip_job){pts, scal, n, 32, c, W, t, threads, winsum};
+            if (t > 0 && pthread_create(&th[t], NULL, ora_pip_worker, &jobs[t]) != 0) rc = ORA_MEMORY_ERROR;
+        }
+        if (ora_pip_worker(&jobs[0]) != NULL) rc = ORA_MEMORY_ERROR;
+        for (int t = 1; t < threads; t++) { void *r = NULL; pthread_join(th[t], &r); if (r) rc = ORA_MEMORY_ERROR; }
+    }
+    if (rc == ORA_SUCCESS) {
+        g1_jac acc;
+        g1_set_inf(&acc);
+        for (int w = W - 1; w >= 0; w--) {
+            for (int d = 0; d < c; d++) g1_dbl(&acc, &acc);
+            g1_add(&acc, &acc, &winsum[w]);
+        }
+        g1_aff r;
+        g1_to_affine(&r, &acc);
+        ora_encode_g1(out, &r);
+    }
+    free(pts); free(scal); free(winsum);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ test helpers */
 /* slow-definition subgroup tests, to validate the endomorphism tests */
 EXPORT int oracle_g1_in_subgroup(const uint8_t in[128], int slow) {

@@ -93,3 +93,14 @@ def pairing_fp12(enc, final_exp=True):
     rc = f(out, bytes(enc), 1 if final_exp else 0)
     assert rc == 0, rc
     return out.raw
+
+
+def g1_pippenger_mt(inp, threads):
+    """All-cores bucket-method MSM: a context number for bench.py, NOT the reference's algorithm."""
+    inp = bytes(inp)
+    out = ctypes.create_string_buffer(128)
+    f = lib().oracle_g1_pippenger_mt
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    rc = f(out, inp, len(inp), threads)
+    return rc, (out.raw if rc == 0 else None)

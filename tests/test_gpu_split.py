@@ -1,0 +1,119 @@
+"""The multi-device split behind the reference ABI (reference src/eip2537.c:541-561 has one
+CPU loop where this library cuts the record range over the listed devices, one host thread each).
+A 1-GPU box rehearses it with EIP2537_HIP_DEVICES=0,0 -- two engine pools on the same GPU -- in a
+fresh process (the device list is read once).  Checked bit-exact against the oracle / the analytic
+goldens, including which error wins when bad records sit in different shards."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import oracle
+from oracle import clib
+import bls12_381 as m
+from blst_eip2537_amd import Eip2537Executor as X, Eip2537Error
+mode = sys.argv[2]
+A, B = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6, 0x0123456789abcdef0fedcba987654321
+def call(fn, inp):
+    try: return 0, fn(inp)
+    except Eip2537Error as e: return e.code, None
+assert X.device_count() == int(sys.argv[3]), X.device_count()
+if mode == "small":                      # EIP2537_HIP_SPLIT_MIN=64: every call below is cut into shards
+    for n in (128, 129, 1000, 4097):
+        g1 = clib.gen_msm_input("g1", n, A, B, 77 + n)
+        assert call(X.g1_multiexp, g1) == clib.call("bls12_g1multiexp", g1), ("g1", n)
+    for n in (130, 777):
+        g2 = clib.gen_msm_input("g2", n, A, B, 99 + n)
+        assert call(X.g2_multiexp, g2) == clib.call("bls12_g2multiexp", g2), ("g2", n)
+    # partial sums that cancel across shards / a shard that is all infinity
+    P = m.g1_mul(m.G1, 0xabcdef)
+    rec = lambda pt, k: m.encode_g1(pt) + m.encode_scalar(k)
+    inp = b"".join(rec(P, 5) for _ in range(64)) + b"".join(rec(m.ec_neg(m.FP, P), 5) for _ in range(64))
+    assert call(X.g1_multiexp, inp) == (0, bytes(128))
+    inp = b"".join(rec(None, 9) for _ in range(64)) + b"".join(rec(P, 1) for _ in range(64))
+    assert call(X.g1_multiexp, inp) == clib.call("bls12_g1multiexp", inp)
+    # error order over shards: the lowest-index bad record wins, whatever shard it is in
+    good = bytearray(clib.gen_msm_input("g1", 256, A, B, 5))
+    bad = bytearray(good); bad[200 * 160 + 0] = 1                    # pad byte: INVALID_ELEMENT in shard 1
+    assert call(X.g1_multiexp, bytes(bad)) == (3, None)
+    bad[10 * 160 + 16:10 * 160 + 128] = m.encode_g1((1, 1))[16:]     # (1,1) off curve in shard 0 -> wins
+    assert call(X.g1_multiexp, bytes(bad)) == (1, None)
+    # pairing: product over shards, and the error order
+    k = 160
+    a0, a1, b0, b1 = 5, 7, 11, 13
+    pairs = bytearray(X.gen_pairing_input(k, a0, a1, b0, b1))
+    s = sum((a0 + i * a1) * (b0 + i * b1) for i in range(k - 1)) % m.R
+    pairs[(k - 1) * 384:] = m.encode_g1(m.g1_mul(m.G1, (-s) % m.R)) + m.encode_g2(m.G2)
+    assert call(X.pairing, bytes(pairs)) == (0, bytes(31) + b"\x01")
+    tw = bytearray(pairs); tw[(k - 1) * 384:(k - 1) * 384 + 128] = m.encode_g1(m.g1_mul(m.G1, (1 - s) % m.R))
+    assert call(X.pairing, bytes(tw)) == (0, bytes(32))
+    rng = m.SplitMix64(3)
+    e = bytearray(pairs)
+    e[150 * 384:150 * 384 + 128] = m.encode_g1(m.random_g1(rng, False))          # non-subgroup G1, shard 1
+    assert call(X.pairing, bytes(e)) == (2, None)
+    e[20 * 384 + 128:20 * 384 + 384] = m.encode_g2((((1, 0)), ((1, 0))))         # off-curve G2, shard 0 -> wins
+    assert call(X.pairing, bytes(e)) == (1, None)
+    assert X.last_plan() is not None
+else:                                    # default thresholds at the BASELINE sizes
+    gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
+    g1 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
+    assert call(X.g1_multiexp, g1) == (0, gold("g1msm_2p20.hex"))
+    p, _ = X.last_timing()
+    assert X.last_plan()["units"] == 1 << 19, X.last_plan()            # each device got half the records
+    g2 = X.gen_msm_input("g2", 1 << 16, A, B, 0x25370100 + 16)
+    assert call(X.g2_multiexp, g2) == (0, gold("g2msm_2p16.hex"))
+    assert X.last_plan()["units"] == 1 << 15, X.last_plan()
+    # below two shards' worth nothing is cut
+    g1s = X.gen_msm_input("g1", 1 << 16, A, B, 0x25370000 + 16)
+    assert call(X.g1_multiexp, g1s) == (0, gold("g1msm_2p16.hex"))
+    assert X.last_plan()["units"] == 1 << 16
+print("split worker ok")
+'''
+
+
+def _run(tmp_path, mode, devices, extra_env):
+    script = tmp_path / "split_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, EIP2537_HIP_DEVICES=devices, **extra_env)
+    env.pop("EIP2537_HIP_DEVICE", None)
+    cp = subprocess.run([sys.executable, str(script), ROOT, mode, str(len(devices.split(",")))], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert cp.returncode == 0 and "split worker ok" in cp.stdout, cp.stdout[-3000:]
+
+
+def test_split_small_inputs_two_pools_one_gpu(tmp_path, clib, X):
+    _run(tmp_path, "small", "0,0", {"EIP2537_HIP_SPLIT_MIN": "64"})
+
+
+def test_split_three_pools_ragged(tmp_path, clib, X):
+    _run(tmp_path, "small", "0,0,0", {"EIP2537_HIP_SPLIT_MIN": "40"})
+
+
+def test_split_baseline_sizes_default_thresholds(tmp_path, clib, X):
+    _run(tmp_path, "full", "0,0", {})
+
+
+def test_device_ordinal_out_of_range_is_an_error(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from blst_eip2537_amd import Eip2537Executor as X, Eip2537Error\n"
+            "try:\n    X.init(63)\n    print('accepted')\nexcept Eip2537Error as e:\n    print('refused', e.code)\n" % ROOT)
+    cp = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "refused 7" in cp.stdout, cp.stdout
+
+
+def test_callers_current_device_is_preserved(X, clib):
+    import torch
+    before = torch.cuda.current_device()
+    inp = clib.gen_msm_input("g1", 100, 3, 5, 1)
+    X.g1_multiexp(inp)
+    assert torch.cuda.current_device() == before
+    assert X.trim(0) >= 0                                  # idle slots give their workspace back
+    assert X.g1_multiexp(inp) == clib.call("bls12_g1multiexp", inp)[1]

@@ -65,6 +65,33 @@ print("rank", rank, "ok")
 '''
 
 
+def test_bench_self_launch_runs_the_ranks(tmp_path, clib, X):
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself (bench.spawn_ranks):
+    the same launcher drives the gloo worker above -- rendezvous on 127.0.0.1, RANK / LOCAL_RANK /
+    WORLD_SIZE per child, worst exit status returned -- and a failing rank fails the launch."""
+    import bench
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    assert bench.spawn_ranks(2, [ROOT], script=str(script)) == 0
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(30)\n")
+    assert bench.spawn_ranks(2, [], script=str(bad)) == 3          # rank 0 is stopped, status of the failed rank
+
+
+def test_bench_gpus_flag_is_not_ignored():
+    """--gpus N must either run N ranks or fail: here (no GPU) every rank refuses to start, and
+    a mismatching WORLD_SIZE is refused instead of being reported as n_gpus = 1."""
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    import torch
+    if not torch.cuda.is_available():
+        assert cp.returncode != 0 and "n_gpus" not in cp.stdout
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert cp.returncode == 2 and "refusing" in cp.stderr and "n_gpus" not in cp.stdout
+
+
 def test_two_rank_gloo_shard_gather_combine(tmp_path, clib, X):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
