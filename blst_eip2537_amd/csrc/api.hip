@@ -350,6 +350,64 @@ template <class F> static int msm_dev_abi(byte *out, const void *d_in, size_t n,
     return msm_entry<F>(pi, out, d_in, n, true, want_partial);
 }
 
+// ---- crossover: calls too small for a launch ------------------------------------
+// The EVM sends mostly tiny inputs (reference README.md:33; bench sizes from 2 pairs up,
+// rust/benches/eip2537_benches.rs:69-70,134,177).  A GPU call costs its fixed chain latency whatever
+// its size (G1 MSM ~0.4 ms, G2 MSM ~1.3 ms, pairing ~2.2 ms: profiles/r02_small_calls.txt), so below
+// the measured crossover the library runs its own host code (curve.h / pairing.h -- the same code the
+// single-pair precompiles use, never anything under oracle/): scalar multiplications added up in
+// record order, and for a pairing the reference's own sequence (src/eip2537.c:1033-1070).  The
+// reference makes the same kind of cut (n == 1 forwards to the mul precompile, :550-552).
+// This is a size rule inside a working engine, not a fallback: without a usable HIP device these
+// calls still fail loudly (the device is selected first), and every size above the crossover has no
+// host path at all.  eip2537_hip_set_route() pins the route for tests.
+static constexpr size_t kHostMaxG1 = 1, kHostMaxG2 = 2, kHostMaxPairs = 2;
+static constexpr size_t kHostRouteTestMax = 64;        // route 1 ("host whenever allowed") still refuses more
+template <class F> struct HostMax { static constexpr size_t kUnits = kHostMaxG1; };
+template <> struct HostMax<Fp2> { static constexpr size_t kUnits = kHostMaxG2; };
+static bool host_route(size_t units, size_t crossover) {
+    const int r = g_route_override.load();
+    if (r == 0) return false;
+    if (r == 1) return units <= kHostRouteTestMax;
+    return units <= crossover;
+}
+static bool device_present() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return device_select_locked();
+}
+template <class F> static int msm_host_small(byte *out, const byte *in, size_t n) {
+    const size_t rec = Wire<F>::kMsmRecWords * 4, pb = Wire<F>::kPointWords * 4;
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (size_t i = 0; i < n; i++, in += rec) {
+        Aff<F> a;
+        int st = host_decode_point<F>(a, in);
+        if (st) return st;                                  // first bad record in input order
+        uint32_t sw[8], k[8];
+        memcpy(sw, in + pb, 32);
+        decode_scalar(k, sw);
+        acc = add(acc, scalar_mul(a, k, 256));
+    }
+    host_encode_point<F>(out, to_affine(acc));
+    return E_SUCCESS;
+}
+static void pairing_finish(byte *out, const Fp12 &ml);
+static int pairing_host_small(byte *out, const byte *in, size_t k) {
+    Fp12 f = fp12_one();
+    for (size_t i = 0; i < k; i++, in += 384) {
+        Aff<Fp> P;
+        Aff<Fp2> Q;
+        int st = host_decode_point<Fp>(P, in);
+        if (st) return st;
+        if (!in_g1(P)) return E_NOT_IN_SUBGROUP;
+        st = host_decode_point<Fp2>(Q, in + 128);
+        if (st) return st;
+        if (!in_g2(Q)) return E_NOT_IN_SUBGROUP;
+        f = mul(f, miller_loop(P, Q));
+    }
+    pairing_finish(out, f);
+    return E_SUCCESS;
+}
+
 // ---- record-range split over the listed devices -------------------------------------
 // A host-input call with at least two shards' worth of records is cut into contiguous ranges, one per
 // listed device; each range is staged and reduced by its own host thread on its own device (its own
@@ -399,6 +457,7 @@ template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_
     const size_t rec = Wire<F>::kMsmRecWords * 4;
     if (in_len == 0 || in_len % rec) return E_INVALID_LENGTH;      // before touching `in`
     const size_t n = in_len / rec;
+    if (host_route(n, HostMax<F>::kUnits)) return device_present() ? msm_host_small<F>(out, in, n) : E_MEMORY_ERROR;
     const std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
     if (pools.empty()) return msm_entry<F>(-1, out, in, n, false, false);
     const size_t shards = pools.size();
@@ -457,6 +516,7 @@ static int pairing_dev_abi(byte *out, const void *d_in, size_t k, bool want_part
 static int pairing_host_abi(byte *out, const byte *in, size_t in_len) {
     if (in_len == 0 || in_len % 384) return E_INVALID_LENGTH;       // before touching `in`
     const size_t k = in_len / 384;
+    if (host_route(k, kHostMaxPairs)) return device_present() ? pairing_host_small(out, in, k) : E_MEMORY_ERROR;
     const std::vector<int> pools = split_plan(k, kPairingSplitMin);
     if (pools.empty()) return pairing_entry(-1, out, in, k, false, false);
     const size_t shards = pools.size();
@@ -699,6 +759,11 @@ API size_t eip2537_hip_trim(size_t keep_bytes) {
         }
     g_cv.notify_all();
     return freed;
+}
+API int eip2537_hip_set_route(int route) {
+    if (route < -1 || route > 1) return E_INVALID_LENGTH;
+    g_route_override.store(route);
+    return 0;
 }
 API int eip2537_hip_set_window(int c) {
     if (c != 0 && (c < 4 || c > 16)) return E_INVALID_LENGTH;

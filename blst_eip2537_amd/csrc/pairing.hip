@@ -106,294 +106,260 @@ __device__ __forceinline__ Xyzz<Fp> g1_mul_zabs4(const Xyzz<Fp> &p, int r, int g
     }
     return acc;
 }
+// One wave per SIMD.  The walk and membership kernels are single-wave blocks, each bound by its own
+// instruction stream; two of them on one SIMD share its issue slots and both run at ~0.7 of their speed
+// while other SIMDs sit idle (measured at 2^12 pairs once the walk stopped needing AGPRs and could
+// co-reside with a membership wave: per-instruction time +25 % / +45 %, k_pair_check_g1 1.12 -> 1.60 ms).
+// Touching the last accumulation register makes a kernel's allocation exceed half of the SIMD's 512
+// registers, so the hardware cannot place a second such wave there and spreads the blocks instead.
+__device__ __forceinline__ void claim_whole_simd() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127");
+#endif
+}
+
+struct Prod4 { Fp2 r0, r1, r2, r3; };      // the four Fp2 products of one round of a lane group
+
+// ---- wire decode, two lanes per pair ------------------------------------------------------------
+// Lane 0 of a pair decodes and validates P (pad / < p / on curve), lane 1 does Q; both store the
+// Montgomery-form point and a "finite and valid" flag.  The walk and membership kernels then start
+// from decoded points: they make no out-of-line calls at all (the decode's ~17 products used the
+// out-of-line Fp product, whose callee-saved registers were the walk kernels' scratch traffic).
+// Error keys: (pair << 4 | stage << 3 | code), stage 0 = G1 (decode, then subgroup), 1 = G2 -- the
+// reference's order inside a pair (src/eip2537.c:1036-1053); atomicMin keeps the first.
+__global__ void __launch_bounds__(256)
+k_pair_decode(const uint32_t *__restrict__ in, uint32_t k, Aff<Fp> *__restrict__ pmont, Aff<Fp2> *__restrict__ qmont,
+              uint8_t *__restrict__ flagP, uint8_t *__restrict__ flagQ, unsigned long long *err) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, i = t >> 1;
+    if (i >= k) return;
+    if ((t & 1u) == 0) {
+        Aff<Fp> P;
+        const int st = decode_point<Fp>(P, in + (size_t)i * kPairWords);
+        if (st != E_SUCCESS) { atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)st); P = Aff<Fp>{fp_zero(), fp_zero()}; }
+        pmont[i] = P;
+        flagP[i] = (st == E_SUCCESS && !is_inf(P)) ? 1 : 0;
+    } else {
+        Aff<Fp2> Q;
+        const int st = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
+        if (st != E_SUCCESS) { atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)st); Q = Aff<Fp2>{fp2_zero(), fp2_zero()}; }
+        qmont[i] = Q;
+        flagQ[i] = (st == E_SUCCESS && !is_inf(Q)) ? 1 : 0;
+    }
+}
+
+// EXCL: one wave per SIMD (batches whose walk + membership waves fit the chip's 1024 SIMDs)
+template <bool EXCL>
 __global__ void __launch_bounds__(64)
-k_pair_check_g1(const uint32_t *__restrict__ in, uint32_t k, unsigned long long *err) {
+k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ flagP, uint32_t k, unsigned long long *err) {
     const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
     const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
+    if (EXCL) claim_whole_simd();
     if (i >= k) return;                                       // uniform in the group
-    Aff<Fp> p;
-    int st = decode_point<Fp>(p, in + (size_t)i * kPairWords);
-    if (st == E_SUCCESS && !is_inf(p)) {
-        // phi(P) == -[z^2]P  (curve.h in_g1)
-        const Xyzz<Fp> t = g1_mul_zabs4(g1_mul_zabs4(from_affine(p), r, gb), r, gb);
-        Aff<Fp> phi_neg{mul(p.x, Fp{{K_BETA}}), neg(p.y)};
-        if (!eq_affine(t, phi_neg)) st = E_NOT_IN_SUBGROUP;
-    }
-    if (st != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)st);
+    if (!flagP[i]) return;                                    // infinity (a member) or already reported by the decode
+    const Aff<Fp> p = pmont[i];
+    // phi(P) == -[z^2]P  (curve.h in_g1)
+    const Xyzz<Fp> t = g1_mul_zabs4(g1_mul_zabs4(from_affine(p), r, gb), r, gb);
+    const Aff<Fp> phi_neg{g1mul(p.x, Fp{{K_BETA}}), neg(p.y)};
+    const bool same = !is_inf(t) && eq(g1mul(phi_neg.x, t.zz), t.x) && eq(g1mul(phi_neg.y, t.zzz), t.y);
+    if (!same && r == 0) atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
-// ---- line walk, 4 lanes per pair --------------------------------------------------------------
-// A lone wave issues one VALU instruction every ~4-8 cycles, so one pair per lane made the
-// 63-step walk a 2400-product serial chain on 64 waves.  Here a pair owns a 4-lane group: every
-// lane keeps the whole running point T, and the independent Fp2 products of a doubling step are
-// dealt one per lane in three rounds ([X^2 Y^2 Z^2 YZ], [B^2 (X+B)^2 E^2 EX], [E ZZ, Z3 ZZ,
-// E(D-X3)]), the results exchanged with shuffles; the cheap linear steps are replicated.
-// same result as miller_dbl_step (pairing.h), products dealt over the 4 lanes of the group
-__device__ __forceinline__ Line miller_dbl_step4(MillerT &T, int r, int gbase) {
-    Fp2 pr = fp2_mul_body(sel4(r, T.x, T.y, T.z, T.y), sel4(r, T.x, T.y, T.z, T.z));   // inlined: hot loop
-    const Fp2 A = shfl_from(pr, gbase), B = shfl_from(pr, gbase + 1), ZZ = shfl_from(pr, gbase + 2), YZ = shfl_from(pr, gbase + 3);
-    const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
-    pr = fp2_mul_body(sel4(r, B, XB, E, E), sel4(r, B, XB, E, T.x));
-    const Fp2 C = shfl_from(pr, gbase), t = shfl_from(pr, gbase + 1), F = shfl_from(pr, gbase + 2), EX = shfl_from(pr, gbase + 3);
-    const Fp2 D = dbl(sub(sub(t, A), C));
-    const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
-    pr = fp2_mul_body(sel4(r, E, Z3, E, E), sel4(r, ZZ, ZZ, sub(D, X3), ZZ));
-    const Fp2 EZ = shfl_from(pr, gbase), Z3ZZ = shfl_from(pr, gbase + 1), Ym = shfl_from(pr, gbase + 2);
+// ---- the addition step and the closing membership test, products dealt over the lanes ---------
+// `prod(a0..a3, b0..b3)` returns the four Fp2 products a_j b_j computed by the lane group (unused slots
+// repeat slot 0).  Same results as miller_add_step (pairing.h); six rounds instead of ~14 replicated
+// Fp2 products per lane.
+template <class PF>
+__device__ __forceinline__ Line miller_add_step_lanes(MillerT &T, const Aff<Fp2> &Q, PF &&prod) {
+    Prod4 pr = prod(T.z, T.z, T.z, T.z, T.z, T.z, T.z, T.z);
+    const Fp2 ZZ = pr.r0;
+    pr = prod(Q.x, ZZ, Q.x, Q.x, ZZ, T.z, ZZ, ZZ);
+    const Fp2 U2 = pr.r0, ZZZ = pr.r1;
+    pr = prod(Q.y, Q.y, Q.y, Q.y, ZZZ, ZZZ, ZZZ, ZZZ);
+    const Fp2 S2 = pr.r0;
+    const Fp2 H = sub(U2, T.x), th = sub(S2, T.y);
+    pr = prod(H, T.z, th, th, H, H, th, Q.x);
+    const Fp2 HH = pr.r0, Z3 = pr.r1, TH2 = pr.r2, thQx = pr.r3;
+    pr = prod(HH, T.x, Z3, HH, H, HH, Q.y, H);
+    const Fp2 HHH = pr.r0, V = pr.r1, Z3Qy = pr.r2;
+    const Fp2 X3 = sub(sub(TH2, HHH), dbl(V));
+    const Fp2 VX = sub(V, X3);
+    pr = prod(th, T.y, th, th, VX, HHH, VX, VX);
     Line l;
-    l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
-    l.a1 = neg(EZ);                   // -3X^2 Z^2
-    l.a4 = Z3ZZ;                      // 2YZ^3
+    l.a0 = sub(thQx, Z3Qy);
+    l.a1 = neg(th);
+    l.a4 = Z3;
     T.x = X3;
-    T.y = sub(Ym, dbl(dbl(dbl(C))));
+    T.y = sub(pr.r0, pr.r1);
     T.z = Z3;
     return l;
 }
-// lanes 0..2 of the pair's group store a0, a1, a4 UNSCALED: multiplying (a1, a4) by (xP, yP) is left
+// T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T:
+//   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
+template <class PF>
+__device__ __forceinline__ bool g2_membership_lanes(const MillerT &T, const Aff<Fp2> &Q, PF &&prod) {
+    const Fp2 cx = conj(Q.x), cy = conj(Q.y);
+    const Fp2 kx{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}}, ky{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}};
+    Prod4 pr = prod(cx, cy, T.z, cx, kx, ky, T.z, kx);
+    const Fp2 px = pr.r0, py = neg(pr.r1), zz = pr.r2;
+    pr = prod(px, zz, px, px, zz, T.z, zz, zz);
+    const Fp2 lhs_x = pr.r0, zzz = pr.r1;
+    pr = prod(py, py, py, py, zzz, zzz, zzz, zzz);
+    return !is_zero(T.z) && eq(lhs_x, T.x) && eq(pr.r0, T.y);
+}
+
+// ---- line walk, 4 / 8 / 16 lanes per pair ------------------------------------------------------
+// A lone wave issues about one VALU instruction every 5-6 cycles, so one pair per lane made the
+// 63-step walk a 2400-product serial chain on 64 waves.  Here a pair owns a lane group: every lane
+// keeps the whole running point T, the independent Fp2 products of a step are dealt over the lanes
+// in rounds of four --
+//   doubling   [X^2  Y^2  Z^2  YZ]   [B^2  (X+B)^2  E^2  EX]   [E ZZ  Z3 ZZ  E(D-X3)]
+//   addition   six rounds (miller_add_step_lanes above)
+// -- and exchanged with wavefront shuffles; the cheap linear steps are replicated on all lanes.
+//   4 lanes:  lane r computes product r whole (Karatsuba, 3 Fp products per round)
+//   8 lanes:  lane pair p, lane q of it computes component q of product p by the schoolbook rule
+//             (c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0: two Fp products per round, no exchange inside
+//             the pair); at 2^12 pairs that is 512 waves, which leaves SIMDs for the G1 membership
+//             kernel running beside it (the 16-lane form fills every SIMD there and the two serialise)
+//   16 lanes: lane 3p+q computes Karatsuba part q of product p (one Fp product per round); the
+//             triple combines them.  Lanes 12..15 shadow product 3.
+template <int LANES> struct WalkLanes;
+template <> struct WalkLanes<4> {
+    int r, gbase;
+    __device__ __forceinline__ WalkLanes(int sl, int gb) : r(sl), gbase(gb) {}
+    __device__ __forceinline__ Prod4 operator()(const Fp2 &a0, const Fp2 &a1, const Fp2 &a2, const Fp2 &a3,
+                                                const Fp2 &b0, const Fp2 &b1, const Fp2 &b2, const Fp2 &b3) const {
+        const Fp2 pr = fp2_mul_body(sel4(r, a0, a1, a2, a3), sel4(r, b0, b1, b2, b3));
+        return Prod4{shfl_from(pr, gbase), shfl_from(pr, gbase + 1), shfl_from(pr, gbase + 2), shfl_from(pr, gbase + 3)};
+    }
+};
+template <> struct WalkLanes<8> {
+    int p, q, gbase;
+    __device__ __forceinline__ WalkLanes(int sl, int gb) : p(sl >> 1), q(sl & 1), gbase(gb) {}
+    __device__ __forceinline__ Prod4 operator()(const Fp2 &a0, const Fp2 &a1, const Fp2 &a2, const Fp2 &a3,
+                                                const Fp2 &b0, const Fp2 &b1, const Fp2 &b2, const Fp2 &b3) const {
+        const Fp2 u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);
+        const Fp y1 = q ? v.c1 : v.c0, y2 = q ? v.c0 : v.c1;
+        const Fp m1 = fp_mul_cols28(u.c0, y1), m2 = fp_mul_cols28(u.c1, y2);
+        const Fp c = q ? add(m1, m2) : sub(m1, m2);
+        Prod4 o;
+        o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
+        o.r1 = Fp2{shfl_from(c, gbase + 2), shfl_from(c, gbase + 3)};
+        o.r2 = Fp2{shfl_from(c, gbase + 4), shfl_from(c, gbase + 5)};
+        o.r3 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
+        return o;
+    }
+};
+template <> struct WalkLanes<16> {
+    int p, q, tb, gbase;
+    __device__ __forceinline__ WalkLanes(int sl, int gb) : p(sl / 3 < 3 ? sl / 3 : 3), q(sl - 3 * (sl / 3)), tb(gb + 3 * (sl / 3 < 3 ? sl / 3 : 3)), gbase(gb) {}
+    __device__ __forceinline__ Prod4 operator()(const Fp2 &a0, const Fp2 &a1, const Fp2 &a2, const Fp2 &a3,
+                                                const Fp2 &b0, const Fp2 &b1, const Fp2 &b2, const Fp2 &b3) const {
+        const Fp2 u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);
+        // this lane's Karatsuba part of its product
+        const Fp x = q == 0 ? u.c0 : (q == 1 ? u.c1 : add(u.c0, u.c1));
+        const Fp y = q == 0 ? v.c0 : (q == 1 ? v.c1 : add(v.c0, v.c1));
+        const Fp t = fp_mul_cols28(x, y);
+        const Fp t0 = shfl_from(t, tb), t1 = shfl_from(t, tb + 1), t2 = shfl_from(t, tb + 2);
+        const Fp c = q == 0 ? sub(t0, t1) : sub(sub(t2, t0), t1);       // lane q=0: c0, lane q=1: c1
+        Prod4 o;
+        o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
+        o.r1 = Fp2{shfl_from(c, gbase + 3), shfl_from(c, gbase + 4)};
+        o.r2 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
+        o.r3 = Fp2{shfl_from(c, gbase + 9), shfl_from(c, gbase + 10)};
+        return o;
+    }
+};
+// Lanes 0..2 of the pair's group store a0, a1, a4 UNSCALED: multiplying (a1, a4) by (xP, yP) is left
 // to the product tree (throughput-rich), which takes one Fp product and ~800 instructions per step
-// off the walk's serial chain
-__device__ __forceinline__ void store_line_raw(LineRec *dst, const Line &l, bool contributes, int sub_lane) {
-    Fp2 v = sub_lane == 0 ? l.a0 : (sub_lane == 1 ? l.a1 : l.a4);
-    if (!contributes) v = sub_lane == 0 ? fp2_one() : fp2_zero();
-    if (sub_lane < 3) (&dst->a0)[sub_lane] = v;
-}
-
-__global__ void __launch_bounds__(64)
-k_pair_lines4(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, Aff<Fp> *__restrict__ pmont,
-              unsigned long long *err) {
-    // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
-    // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
-    __shared__ Aff<Fp2> sQ[16];
-    const int lane = threadIdx.x & 63, r = lane & 3, gbase = lane & ~3, gi = lane >> 2;
-    const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
-    bool q_live = false, contributes = false;
-    MillerT T;
-    if (i < k) {                              // uniform within a 4-lane group
-        Aff<Fp> P;
-        Aff<Fp2> Q;
-        int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
-        int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
-        if (s2 != E_SUCCESS && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
-        q_live = s2 == E_SUCCESS && !is_inf(Q);
-        contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-        if (r == 0) { pmont[i] = P; sQ[gi] = Q; }
-        T = MillerT{Q.x, Q.y, fp2_one()};
-    }
-    __syncthreads();
-    if (i >= k) return;
-    if (!q_live) {
-        if (r < 3) {
-            Fp2 v = r == 0 ? fp2_one() : fp2_zero();
-            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[r] = v;
-        }
-        return;
-    }
-    const uint64_t z = K_Z_ABS;
-    int s = 0;
-    for (int bit = 62; bit >= 0; bit--) {
-        Line l = miller_dbl_step4(T, r, gbase);
-        store_line_raw(&lines[(size_t)s * k + i], l, contributes, r);
-        s++;
-        if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the 4 lanes
-            Aff<Fp2> Q = sQ[gi];
-            l = miller_add_step(T, Q);
-            store_line_raw(&lines[(size_t)s * k + i], l, contributes, r);
-            s++;
-        }
-    }
-    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T
-    //   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
-    Aff<Fp2> Q = sQ[gi];
-    Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
-    Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
-    Fp2 zz = sqr(T.z);
-    bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
-    if (!in_sub && r == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
-}
-
-// ---- line walk, 16 lanes per pair -------------------------------------------------------------
-// A lone wave issues one VALU instruction every ~4-8 cycles, so one pair per lane made the
-// 63-step walk a 2400-product serial chain on 64 waves.  Here a pair owns a 16-lane group: every
-// lane keeps the whole running point T, and the independent Fp2 products of a doubling step
-//   round 1 [X^2  Y^2  Z^2  YZ]   round 2 [B^2  (X+B)^2  E^2  EX]   round 3 [E ZZ  Z3 ZZ  E(D-X3)]
-// are dealt over 12 lanes, ONE Fp product each: lane 3p+q computes Karatsuba part q of product p
-// (a0 b0, a1 b1, (a0+a1)(b0+b1)); the triple combines them and the four Fp2 results are
-// broadcast with shuffles.  The cheap linear steps are replicated on all lanes.
-struct Prod4 { Fp2 r0, r1, r2, r3; };
-__device__ __forceinline__ Prod4 fp2_products4(const Fp2 &u, const Fp2 &v, int q, int tb, int gbase) {
-    // this lane's Karatsuba part of its product (operands u, v already selected by product index)
-    const Fp x = q == 0 ? u.c0 : (q == 1 ? u.c1 : add(u.c0, u.c1));
-    const Fp y = q == 0 ? v.c0 : (q == 1 ? v.c1 : add(v.c0, v.c1));
-    const Fp t = fp_mul_cols28(x, y);
-    const Fp t0 = shfl_from(t, tb), t1 = shfl_from(t, tb + 1), t2 = shfl_from(t, tb + 2);
-    const Fp c = q == 0 ? sub(t0, t1) : sub(sub(t2, t0), t1);       // lane q=0: c0, lane q=1: c1
-    Prod4 o;
-    o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
-    o.r1 = Fp2{shfl_from(c, gbase + 3), shfl_from(c, gbase + 4)};
-    o.r2 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
-    o.r3 = Fp2{shfl_from(c, gbase + 9), shfl_from(c, gbase + 10)};
-    return o;
-}
-// same result as miller_dbl_step (pairing.h)
-__device__ __forceinline__ Line miller_dbl_step16(MillerT &T, int p, int q, int tb, int gbase) {
-    Prod4 pr = fp2_products4(sel4(p, T.x, T.y, T.z, T.y), sel4(p, T.x, T.y, T.z, T.z), q, tb, gbase);
-    const Fp2 A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
-    const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
-    pr = fp2_products4(sel4(p, B, XB, E, E), sel4(p, B, XB, E, T.x), q, tb, gbase);
-    const Fp2 C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
-    const Fp2 D = dbl(sub(sub(t, A), C));
-    const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
-    pr = fp2_products4(sel4(p, E, Z3, E, E), sel4(p, ZZ, ZZ, sub(D, X3), ZZ), q, tb, gbase);
-    const Fp2 EZ = pr.r0, Z3ZZ = pr.r1, Ym = pr.r2;
-    Line l;
-    l.a0 = sub(EX, dbl(B));           // 3X^3 - 2Y^2
-    l.a1 = neg(EZ);                   // -3X^2 Z^2
-    l.a4 = Z3ZZ;                      // 2YZ^3
-    T.x = X3;
-    T.y = sub(Ym, dbl(dbl(dbl(C))));
-    T.z = Z3;
-    return l;
-}
-__global__ void __launch_bounds__(64)
-k_pair_lines16(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, Aff<Fp> *__restrict__ pmont,
-              unsigned long long *err) {
-    // P and Q are only needed for the line scaling, the 5 addition steps and the final membership
-    // test: they wait in LDS (288 B per pair) instead of occupying 72 VGPRs through the walk
-    __shared__ Aff<Fp2> sQ[4];
-    const int lane = threadIdx.x & 63, sl = lane & 15, gbase = lane & ~15, gi = lane >> 4;
-    const int pidx = sl / 3 < 3 ? sl / 3 : 3, q = sl - 3 * (sl / 3), tb = gbase + 3 * pidx;   // lanes 12..15 shadow product 3
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 4);
-    bool q_live = false, contributes = false;
-    MillerT T;
-    if (i < k) {                              // uniform within a 16-lane group
-        Aff<Fp> P;
-        Aff<Fp2> Q;
-        int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
-        int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
-        if (s2 != E_SUCCESS && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
-        q_live = s2 == E_SUCCESS && !is_inf(Q);
-        contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-        if (sl == 0) { pmont[i] = P; sQ[gi] = Q; }
-        T = MillerT{Q.x, Q.y, fp2_one()};
-    }
-    __syncthreads();
-    if (i >= k) return;
-    if (!q_live) {
-        if (sl < 3) {
-            Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
-            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[sl] = v;
-        }
-        return;
-    }
-    const uint64_t z = K_Z_ABS;
-    int s = 0;
-    for (int bit = 62; bit >= 0; bit--) {
-        Line l = miller_dbl_step16(T, pidx, q, tb, gbase);
-        store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
-        s++;
-        if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
-            Aff<Fp2> Q = sQ[gi];
-            l = miller_add_step(T, Q);
-            store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
-            s++;
-        }
-    }
-    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T
-    //   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
-    Aff<Fp2> Q = sQ[gi];
-    Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
-    Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
-    Fp2 zz = sqr(T.z);
-    bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
-    if (!in_sub && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
-}
-
-// ---- line walk, 8 lanes per pair --------------------------------------------------------------
-// Between the two forms above: the four Fp2 products of a round go to four lane PAIRS, lane q of a
-// pair computing component q of its product by the schoolbook rule (c0 = a0 b0 - a1 b1,
-// c1 = a0 b1 + a1 b0: two Fp products per lane and no exchange inside the pair), so a doubling
-// step is 6 Fp-product times per lane instead of 9 (4 lanes) at half the waves of the 16-lane
-// form -- at 2^12 pairs that is 512 waves, which leaves SIMDs for the G1 membership kernel
-// running beside it (the 16-lane form fills every SIMD there and the two kernels serialise).
-__device__ __forceinline__ Prod4 fp2_products8(const Fp2 &u, const Fp2 &v, int q, int gbase) {
-    const Fp y1 = q ? v.c1 : v.c0, y2 = q ? v.c0 : v.c1;
-    const Fp m1 = fp_mul_cols28(u.c0, y1), m2 = fp_mul_cols28(u.c1, y2);
-    const Fp c = q ? add(m1, m2) : sub(m1, m2);
-    Prod4 o;
-    o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
-    o.r1 = Fp2{shfl_from(c, gbase + 2), shfl_from(c, gbase + 3)};
-    o.r2 = Fp2{shfl_from(c, gbase + 4), shfl_from(c, gbase + 5)};
-    o.r3 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
-    return o;
+// off the walk's serial chain.  A pair that contributes the identity stores the line 1.
+__device__ __forceinline__ void store_line_part(LineRec *dst, int part, const Fp2 &v, bool contributes, int sl) {
+    if (sl == part) (&dst->a0)[part] = contributes ? v : (part == 0 ? fp2_one() : fp2_zero());
 }
 // same result as miller_dbl_step (pairing.h); the line coefficients are stored as soon as they exist
 // (a0 after the second round) so that their operands do not stay live through the third
-__device__ __forceinline__ void miller_dbl_step8(MillerT &T, int p, int q, int gbase, LineRec *dst, bool contributes, int sl) {
-    Prod4 pr = fp2_products8(sel4(p, T.x, T.y, T.z, T.y), sel4(p, T.x, T.y, T.z, T.z), q, gbase);
+template <class PF>
+__device__ __forceinline__ void miller_dbl_step_lanes(MillerT &T, PF &&prod, LineRec *dst, bool contributes, int sl) {
+    Prod4 pr = prod(T.x, T.y, T.z, T.y, T.x, T.y, T.z, T.z);
     const Fp2 A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
     const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
-    pr = fp2_products8(sel4(p, B, XB, E, E), sel4(p, B, XB, E, T.x), q, gbase);
+    pr = prod(B, XB, E, E, B, XB, E, T.x);
     const Fp2 C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
-    if (sl == 0) dst->a0 = contributes ? sub(EX, dbl(B)) : fp2_one();          // 3X^3 - 2Y^2
+    store_line_part(dst, 0, sub(EX, dbl(B)), contributes, sl);                   // 3X^3 - 2Y^2
     const Fp2 D = dbl(sub(sub(t, A), C));
     const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
     const Fp2 C8 = dbl(dbl(dbl(C)));
-    pr = fp2_products8(sel4(p, E, Z3, E, E), sel4(p, ZZ, ZZ, sub(D, X3), ZZ), q, gbase);
-    const Fp2 EZ = pr.r0, Z3ZZ = pr.r1, Ym = pr.r2;
-    if (sl == 1) dst->a1 = contributes ? neg(EZ) : fp2_zero();                 // -3X^2 Z^2
-    if (sl == 2) dst->a4 = contributes ? Z3ZZ : fp2_zero();                    // 2YZ^3
+    pr = prod(E, Z3, E, E, ZZ, ZZ, sub(D, X3), ZZ);
+    store_line_part(dst, 1, neg(pr.r0), contributes, sl);                        // -3X^2 Z^2
+    store_line_part(dst, 2, pr.r1, contributes, sl);                             // 2YZ^3
     T.x = X3;
-    T.y = sub(Ym, C8);
+    T.y = sub(pr.r2, C8);
     T.z = Z3;
 }
-
-__global__ void __launch_bounds__(64)
-k_pair_lines8(const uint32_t *__restrict__ in, uint32_t k, LineRec *__restrict__ lines, Aff<Fp> *__restrict__ pmont,
-              unsigned long long *err) {
-    __shared__ Aff<Fp2> sQ[8];
-    const int lane = threadIdx.x & 63, sl = lane & 7, gbase = lane & ~7, gi = lane >> 3;
-    const int pidx = sl >> 1, q = sl & 1;
-    const uint32_t i = blockIdx.x * 8u + (threadIdx.x >> 3);
+template <int LANES>
+__device__ __forceinline__ void pair_walk(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP,
+                                          const uint8_t *__restrict__ flagQ, uint32_t k, LineRec *__restrict__ lines,
+                                          unsigned long long *err, Aff<Fp2> *sQ) {
+    constexpr int kGroups = 64 / LANES;
+    const int lane = threadIdx.x & 63, sl = lane & (LANES - 1), gbase = lane & ~(LANES - 1), gi = lane / LANES;
+    const uint32_t i = blockIdx.x * (uint32_t)kGroups + (uint32_t)gi;
+    // Q is only needed by the 5 addition steps and the closing membership test: it waits in LDS
+    // (192 B per pair) instead of occupying 48 VGPRs through the walk
     bool q_live = false, contributes = false;
     MillerT T;
-    if (i < k) {                              // uniform within an 8-lane group
-        Aff<Fp> P;
-        Aff<Fp2> Q;
-        int s1 = decode_point<Fp>(P, in + (size_t)i * kPairWords);
-        int s2 = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
-        if (s2 != E_SUCCESS && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)s2);
-        q_live = s2 == E_SUCCESS && !is_inf(Q);
-        contributes = q_live && s1 == E_SUCCESS && !is_inf(P);   // else the pair contributes 1
-        if (sl == 0) { pmont[i] = P; sQ[gi] = Q; }
+    if (LANES >= 8) claim_whole_simd();       // the forms used while the batch fits one wave per SIMD
+    if (i < k) {                              // uniform within a lane group
+        q_live = flagQ[i] != 0;
+        contributes = q_live && flagP[i] != 0;                   // else the pair contributes 1
+        const Aff<Fp2> Q = qmont[i];
+        if (sl == 0) sQ[gi] = Q;
         T = MillerT{Q.x, Q.y, fp2_one()};
     }
     __syncthreads();
     if (i >= k) return;
-    if (!q_live) {
+    if (!q_live) {                            // Q at infinity (or undecodable: reported by the decode)
         if (sl < 3) {
-            Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
+            const Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
             for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[sl] = v;
         }
         return;
     }
+    const WalkLanes<LANES> prod(sl, gbase);
     const uint64_t z = K_Z_ABS;
     int s = 0;
     for (int bit = 62; bit >= 0; bit--) {
-        miller_dbl_step8(T, pidx, q, gbase, &lines[(size_t)s * k + i], contributes, sl);
+        miller_dbl_step_lanes(T, prod, &lines[(size_t)s * k + i], contributes, sl);
         s++;
-        if ((z >> bit) & 1ull) {              // 5 of 63 steps: replicated on the lanes of the group
-            Aff<Fp2> Q = sQ[gi];
-            Line l = miller_add_step(T, Q);
-            store_line_raw(&lines[(size_t)s * k + i], l, contributes, sl);
+        if ((z >> bit) & 1ull) {              // 5 of 63 steps
+            const Aff<Fp2> Q = sQ[gi];
+            const Line l = miller_add_step_lanes(T, Q, prod);
+            LineRec *dst = &lines[(size_t)s * k + i];
+            store_line_part(dst, 0, l.a0, contributes, sl);
+            store_line_part(dst, 1, l.a1, contributes, sl);
+            store_line_part(dst, 2, l.a4, contributes, sl);
             s++;
         }
     }
-    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T      (blst_p2_affine_in_g2, reference :1051)
-    Aff<Fp2> Q = sQ[gi];
-    Fp2 px = mul(conj(Q.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}});
-    Fp2 py = neg(mul(conj(Q.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}));
-    Fp2 zz = sqr(T.z);
-    bool in_sub = !is_zero(T.z) && eq(mul(px, zz), T.x) && eq(mul(py, mul(zz, T.z)), T.y);
-    if (!in_sub && sl == 0) atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+    const Aff<Fp2> Q = sQ[gi];
+    if (!g2_membership_lanes(T, Q, prod) && sl == 0)
+        atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+}
+__global__ void __launch_bounds__(64)
+k_pair_lines4(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
+              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+    __shared__ Aff<Fp2> sQ[16];
+    pair_walk<4>(qmont, flagP, flagQ, k, lines, err, sQ);
+}
+__global__ void __launch_bounds__(64)
+k_pair_lines8(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
+              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+    __shared__ Aff<Fp2> sQ[8];
+    pair_walk<8>(qmont, flagP, flagQ, k, lines, err, sQ);
+}
+__global__ void __launch_bounds__(64)
+k_pair_lines16(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
+               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+    __shared__ Aff<Fp2> sQ[4];
+    pair_walk<16>(qmont, flagP, flagQ, k, lines, err, sQ);
 }
 
 // ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
@@ -608,11 +574,14 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     const uint32_t tree_blocks = (uint32_t)((k + 32 * group_lines - 1) / (32 * group_lines));
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->pts.reserve(k * sizeof(Aff<Fp>)));
+    HIPCHK(e->digits.reserve(k * sizeof(Aff<Fp2>) + 2 * k + 64));      // decoded Q of every pair, then the two flag arrays
     HIPCHK(e->partial.reserve((size_t)kSteps * k * sizeof(LineRec)));
     HIPCHK(e->winout.reserve(((size_t)kSteps * tree_blocks + kSteps) * sizeof(Fp12)));
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *lines = reinterpret_cast<LineRec *>(e->partial.p);
     auto *pmont = reinterpret_cast<Aff<Fp> *>(e->pts.p);               // P of every pair, Montgomery form
+    auto *qmont = reinterpret_cast<Aff<Fp2> *>(e->digits.p);
+    auto *flagP = reinterpret_cast<uint8_t *>(qmont + k), *flagQ = flagP + k;
     auto *blk_out = reinterpret_cast<Fp2 *>(e->winout.p);                 // [step][block] tower-layout Fp12
     auto *step_out = blk_out + (size_t)kSteps * tree_blocks * 6;           // [step] Fp12
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
@@ -626,14 +595,20 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipStream_t s = e->stream;
     HIPCHK(hipMemsetAsync(err, 0xFF, 8, s));
     HIPCHK(hipEventRecord(e->ev_start, s));
+    hipLaunchKernelGGL(k_pair_decode, dim3((uint32_t)((2 * k + 255) / 256)), dim3(256), 0, s, in, (uint32_t)k, pmont, qmont, flagP, flagQ, err);
+    HIPCHK(hipEventRecord(e->ev_j3, s));
     // fork: the G1 membership kernel runs beside the line walk
-    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_start, 0));
-    hipLaunchKernelGGL(k_pair_check_g1, dim3((uint32_t)((k + 15) / 16)), dim3(64), 0, e->stream2, in, (uint32_t)k, err);
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_j3, 0));
+    const uint32_t check_blocks = (uint32_t)((k + 15) / 16);
+    if (line_blocks + check_blocks <= 1024u)
+        hipLaunchKernelGGL(k_pair_check_g1<true>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err);
+    else
+        hipLaunchKernelGGL(k_pair_check_g1<false>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err);
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
-    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
-    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
-    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, in, (uint32_t)k, lines, pmont, err);
+    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err);
+    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err);
+    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err);
     HIPCHK(hipEventRecord(e->ev_b, s));
     // one block per step (k <= 32 group_lines): its output IS L_s, same [step][6] layout as step_out
     hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k,

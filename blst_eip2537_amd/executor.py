@@ -88,6 +88,8 @@ def lib():
         f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     L.eip2537_hip_init.restype = ctypes.c_int
     L.eip2537_hip_init.argtypes = [ctypes.c_int]
+    L.eip2537_hip_set_route.restype = ctypes.c_int
+    L.eip2537_hip_set_route.argtypes = [ctypes.c_int]
     L.eip2537_hip_set_window.restype = ctypes.c_int
     L.eip2537_hip_set_window.argtypes = [ctypes.c_int]
     L.eip2537_hip_device_count.restype = ctypes.c_int
@@ -227,6 +229,13 @@ class Eip2537Executor:
     @staticmethod
     def trim(keep_bytes=0):
         return int(lib().eip2537_hip_trim(keep_bytes))
+
+    @staticmethod
+    def set_route(route):
+        """-1: default crossover; 0: always the GPU; 1: the library's host code up to 64 units."""
+        rc = lib().eip2537_hip_set_route(route)
+        if rc != 0:
+            raise Eip2537Error(rc)
 
     @staticmethod
     def set_window(c):

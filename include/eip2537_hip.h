@@ -79,6 +79,12 @@ int eip2537_hip_gen_g2_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32],
 int eip2537_hip_gen_pairing_input(uint8_t *out, size_t k, const uint8_t a0[32], const uint8_t a1[32],
                                   const uint8_t b0[32], const uint8_t b1[32], uint64_t start);
 
+/* Testing hook for the small-call crossover: the reference-ABI multiexp / pairing calls run the
+ * library's own host code below a measured size (G1 MSM 1 record -- where the reference itself
+ * forwards to bls12_g1mul, src/eip2537.c:550-552 --, G2 MSM 2 records, pairing 2 pairs) and the GPU
+ * above it.  route = 0: always the GPU; 1: the host code up to 64 units; -1: the default rule. */
+int eip2537_hip_set_route(int route);
+
 /* Testing hook: force the Pippenger window width (4..16); 0 restores the cost model. */
 int eip2537_hip_set_window(int c);
 
