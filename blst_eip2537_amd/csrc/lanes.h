@@ -6,6 +6,20 @@
 
 namespace eip {
 
+// One wave per SIMD.  The chain-bound kernels (pairing line walk and G1 membership, MSM bucket reduce)
+// run few waves, each bound by its own instruction stream; two of them on one SIMD share its issue
+// slots and both run at ~0.7 of their speed while other SIMDs sit idle -- and the dispatcher does place
+// them so whenever their register counts allow (measured at 2^12 pairs once the walk stopped needing
+// AGPRs and could co-reside with a membership wave: per-instruction time +25 % / +45 %,
+// k_pair_check_g1 1.12 -> 1.60 ms; with the claim 1.07 ms and the walk 1.73 -> 1.46 ms).
+// Touching the last accumulation register makes a kernel's allocation exceed half of the SIMD's 512
+// registers, so the hardware cannot place a second such wave there and spreads the blocks instead.
+__device__ __forceinline__ void claim_whole_simd() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127");
+#endif
+}
+
 __device__ __forceinline__ Fp shfl_from(const Fp &a, int src) {
     Fp r;
 #pragma unroll

@@ -548,18 +548,31 @@ k_msm_fold_small4(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ ta
     }
 }
 
-// grid (blocks, W); 256 threads = 64 four-lane groups, one segment of S buckets per group
+// Reduce grids are one-dimensional and hold only working blocks: `bn` blocks for each of the W - 1 signed
+// windows, then the top window's (it can have twice the buckets; a (blocks, W) grid sized for it left
+// half of the other windows' blocks idle -- and an idle block still takes a SIMD from a working one).
+// Block b's output is winout[b]; the host knows the same map.
+struct ReduceGrid { uint32_t bn, bt; };
+__device__ __forceinline__ void reduce_block_to_window(const ReduceGrid &rg, const MsmPlan &pl, int &w, uint32_t &bx) {
+    const uint32_t b = blockIdx.x, body = (uint32_t)(pl.W - 1) * rg.bn;
+    if (b < body) { w = (int)(b / rg.bn); bx = b - (uint32_t)w * rg.bn; }
+    else { w = pl.W - 1; bx = b - body; }
+}
+// 256 threads = 64 four-lane groups, one segment of S buckets per group
 template <class F>
 __global__ void __launch_bounds__(256, 1)      // latency-bound chain: registers over occupancy
-k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl,
+k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
              Xyzz<F> *__restrict__ winout_) {
     using T = typename AccumField<F>::T;
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
     Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
-    const int w = blockIdx.y;
+    int w;
+    uint32_t bx;
+    reduce_block_to_window(rg, pl, w, bx);
+    claim_whole_simd();                            // one wave per SIMD (lanes.h)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
     const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
-    const uint32_t seg = blockIdx.x * 64u + (threadIdx.x >> 2);
+    const uint32_t seg = bx * 64u + (threadIdx.x >> 2);
     const uint32_t lo = seg * pl.S;
     Xyzz<T> C = xyzz_inf<T>();
     if (lo < nbw) {                                            // uniform in the group
@@ -584,7 +597,7 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (wave == 0 && lane < 4) {
         for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
-        if (lane == 0) winout[(size_t)w * gridDim.x + blockIdx.x] = C;
+        if (lane == 0) winout[blockIdx.x] = C;
     }
 }
 
@@ -594,14 +607,17 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
 // products are 3x heavier and the 4-lane form wins 2.2 ms to 7.0 ms at 2^16.
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl,
+k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
               Xyzz<F> *__restrict__ winout_) {
     using T = typename AccumField<F>::T;
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
     Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
-    const int w = blockIdx.y;
+    int w;
+    uint32_t bx;
+    reduce_block_to_window(rg, pl, w, bx);
+    claim_whole_simd();                            // one wave per SIMD (lanes.h)
     const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
-    const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t seg = bx * 256u + threadIdx.x;
     const uint32_t lo = seg * pl.S;
     Xyzz<T> C = xyzz_inf<T>();
     if (lo < nbw) {
@@ -634,7 +650,7 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; k++) xyzz_add_o<T>(&C, &C, &sm[k]);
-        winout[(size_t)w * gridDim.x + blockIdx.x] = C;
+        winout[blockIdx.x] = C;
     }
 }
 
@@ -688,12 +704,18 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // c = 16 (557 K buckets) four lanes per segment would oversubscribe the SIMDs and lose.
     const bool four = ReduceCfg<F>::kFourLane || pl.NB <= kFourLaneMaxBuckets;
     const uint32_t seg_per_block = four ? 64u : 256u;
-    if (four) pl.S = std::max(1u, (pl.NB + 64u * 232u - 1u) / (64u * 232u));
-    else pl.S = std::max(2u, (pl.NB + 256u * 140u - 1u) / (256u * 140u));   // ~140 working blocks (0.5 wave/SIMD):
-                                                                            // measured optimum, more waves contend on stack traffic
-    const uint32_t seg_per_win = (std::max(pl.B, pl.BT) + pl.S - 1) / pl.S;
-    const uint32_t red_blocks = (seg_per_win + seg_per_block - 1u) / seg_per_block;
-    const size_t nwin_out = (size_t)pl.W * red_blocks;
+    // Segment length S: the shortest chain whose blocks (4 waves each, one wave per SIMD: both kernels
+    // claim the whole SIMD) still fit the chip in one round -- 256 CUs x 4 SIMDs.  The grid holds
+    // working blocks only, so the target is close to that limit (before: a (blocks, W) grid sized for
+    // the top window, half of it idle, and ~140 working blocks: 2^20 reduce 1.42 ms, S = 16).
+    static const uint32_t env_rb = [] { const char *v = getenv("EIP2537_REDUCE_BLOCKS"); return v ? (uint32_t)atoi(v) : 0u; }();
+    const uint32_t block_target = env_rb ? env_rb : (four ? 232u : 240u);
+    pl.S = std::max(four ? 1u : 2u, (pl.NB + seg_per_block * block_target - 1u) / (seg_per_block * block_target));
+    ReduceGrid rg;
+    rg.bn = ((pl.B + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
+    rg.bt = ((pl.BT + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
+    const uint32_t red_blocks = (uint32_t)(pl.W - 1) * rg.bn + rg.bt;
+    const size_t nwin_out = red_blocks;
 
     HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
@@ -771,9 +793,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
     if (four)
-        hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
+        hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else
-        hipLaunchKernelGGL(k_msm_reduce1<F>, dim3(red_blocks, pl.W), dim3(256), 0, s, partial, taskoff, pl, winout);
+        hipLaunchKernelGGL(k_msm_reduce1<F>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
@@ -791,7 +813,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     Xyzz<F> acc = xyzz_inf<F>();
     for (int w = pl.W - 1; w >= 0; w--) {
         for (int d = 0; d < pl.c; d++) acc = dbl(acc);
-        for (uint32_t b = 0; b < red_blocks; b++) acc = add(acc, hw[(size_t)w * red_blocks + b]);
+        const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
+        for (uint32_t b = 0; b < nb; b++) acc = add(acc, hw[b0 + b]);
     }
     memcpy(partial_words, &acc, sizeof acc);
     return E_SUCCESS;

@@ -106,18 +106,6 @@ __device__ __forceinline__ Xyzz<Fp> g1_mul_zabs4(const Xyzz<Fp> &p, int r, int g
     }
     return acc;
 }
-// One wave per SIMD.  The walk and membership kernels are single-wave blocks, each bound by its own
-// instruction stream; two of them on one SIMD share its issue slots and both run at ~0.7 of their speed
-// while other SIMDs sit idle (measured at 2^12 pairs once the walk stopped needing AGPRs and could
-// co-reside with a membership wave: per-instruction time +25 % / +45 %, k_pair_check_g1 1.12 -> 1.60 ms).
-// Touching the last accumulation register makes a kernel's allocation exceed half of the SIMD's 512
-// registers, so the hardware cannot place a second such wave there and spreads the blocks instead.
-__device__ __forceinline__ void claim_whole_simd() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127");
-#endif
-}
-
 struct Prod4 { Fp2 r0, r1, r2, r3; };      // the four Fp2 products of one round of a lane group
 
 // ---- wire decode, two lanes per pair ------------------------------------------------------------
