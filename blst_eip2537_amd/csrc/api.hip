@@ -353,7 +353,7 @@ template <class F> static int msm_dev_abi(byte *out, const void *d_in, size_t n,
 // ---- crossover: calls too small for a launch ------------------------------------
 // The EVM sends mostly tiny inputs (reference README.md:33; bench sizes from 2 pairs up,
 // rust/benches/eip2537_benches.rs:69-70,134,177).  A GPU call costs its fixed chain latency whatever
-// its size (G1 MSM ~0.4 ms, G2 MSM ~1.3 ms, pairing ~2.2 ms: profiles/r02_small_calls.txt), so below
+// its size (G1 MSM ~0.37 ms, G2 MSM ~0.9 ms, pairing ~1.9 ms: profiles/r02_small_calls.txt), so below
 // the measured crossover the library runs its own host code (curve.h / pairing.h -- the same code the
 // single-pair precompiles use, never anything under oracle/): scalar multiplications added up in
 // record order, and for a pairing the reference's own sequence (src/eip2537.c:1033-1070).  The
@@ -361,7 +361,7 @@ template <class F> static int msm_dev_abi(byte *out, const void *d_in, size_t n,
 // This is a size rule inside a working engine, not a fallback: without a usable HIP device these
 // calls still fail loudly (the device is selected first), and every size above the crossover has no
 // host path at all.  eip2537_hip_set_route() pins the route for tests.
-static constexpr size_t kHostMaxG1 = 1, kHostMaxG2 = 2, kHostMaxPairs = 2;
+static constexpr size_t kHostMaxG1 = 2, kHostMaxG2 = 2, kHostMaxPairs = 4;
 static constexpr size_t kHostRouteTestMax = 64;        // route 1 ("host whenever allowed") still refuses more
 template <class F> struct HostMax { static constexpr size_t kUnits = kHostMaxG1; };
 template <> struct HostMax<Fp2> { static constexpr size_t kUnits = kHostMaxG2; };
@@ -405,6 +405,136 @@ static int pairing_host_small(byte *out, const byte *in, size_t k) {
         f = mul(f, miller_loop(P, Q));
     }
     pairing_finish(out, f);
+    return E_SUCCESS;
+}
+
+// ---- coalescing of concurrent small MSM calls -------------------------------------
+// A small GPU call is all fixed latency (~0.4-0.55 ms for anything up to a few hundred records), and the
+// real callers are concurrent (goroutines / test threads under an EVM).  So small host-input MSMs do
+// not each take an engine: a caller queues its request, and whichever waiting caller finds a free
+// "flight" becomes the leader of everything queued at that moment -- one staging copy, ONE device
+// pipeline over the concatenated records with per-call bucket ranges and per-call error words
+// (msm.hip, "coalesced batch") -- then hands every caller its 32 window sums; each caller finishes its
+// own Horner, inversion and encoding on its own thread.  Batches form by themselves: while the flights
+// are busy, arrivals pile up for the next leader; an uncontended caller leads a batch of one, which
+// takes the ordinary single-call path.  $EIP2537_HIP_COALESCE=0 turns the queue off.
+template <class F> struct CoalesceCfg { static constexpr size_t kMinRecords = 2, kMaxRecords = 512; };
+// Device pipelines allowed in flight for these calls, by how many callers are outstanding (queued or being
+// served): few callers each get a pipeline at once (what the engine slots gave them before); the more
+// callers pile up, the fewer and larger the batches (measured, 128-record G1 calls: 64 callers 28 k
+// calls/s with 2 flights, 20 k with 4, 7 k uncoalesced; 4 callers 6.6 k with >= 4 flights, 3.8 k with 2).
+static int coalesce_flights(size_t outstanding) { return outstanding <= 8 ? 8 : outstanding <= 24 ? 4 : 2; }
+static std::atomic<uint64_t> g_co_batches{0}, g_co_calls{0}, g_co_max{0};   // device pipelines run / calls served / largest batch
+static constexpr size_t kCoalesceMaxRecords = 16384;          // per batch
+template <class F> struct MsmReq {
+    const byte *in = nullptr;
+    size_t n = 0;
+    Xyzz<F> wins[kMsmBatchWindows];
+    Xyzz<F> whole;                   // batch of one: the ordinary pipeline's partial sum
+    bool have_whole = false;
+    int rc = E_MEMORY_ERROR;
+    bool taken = false, done = false;
+};
+template <class F> struct Batcher {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<MsmReq<F> *> pending;
+    int in_flight = 0;           // device pipelines running
+    size_t served = 0;           // calls inside those pipelines
+};
+template <class F> static Batcher<F> &batcher() { static Batcher<F> b; return b; }
+static bool coalesce_enabled() {
+    static const bool on = [] { const char *v = getenv("EIP2537_HIP_COALESCE"); return !v || atoi(v) != 0; }();
+    return on;
+}
+template <class F> static int msm_batch_dispatch(Engine *e, const void *d_in, const uint32_t *coff, int M, Xyzz<F> *wins, int *rc);
+template <> int msm_batch_dispatch<Fp>(Engine *e, const void *d_in, const uint32_t *coff, int M, Xyzz<Fp> *wins, int *rc) {
+    return msm_g1_batch_device(e, d_in, coff, M, reinterpret_cast<uint32_t *>(wins), rc);
+}
+template <> int msm_batch_dispatch<Fp2>(Engine *e, const void *d_in, const uint32_t *coff, int M, Xyzz<Fp2> *wins, int *rc) {
+    return msm_g2_batch_device(e, d_in, coff, M, reinterpret_cast<uint32_t *>(wins), rc);
+}
+template <class F> static void run_msm_batch(std::vector<MsmReq<F> *> &batch) {
+    const size_t rec = Wire<F>::kMsmRecWords * 4;
+    const int M = (int)batch.size();
+    SlotLease lease(-1);
+    Engine *e = lease.e;
+    if (!e) { for (auto *r : batch) r->rc = E_MEMORY_ERROR; return; }
+    if (M == 1) {                       // nobody to share with: the ordinary pipeline
+        MsmReq<F> *r = batch[0];
+        int st = stage_input(e, r->in, r->n * rec);
+        if (!st) st = msm_dispatch<F>(e, e->input.p, r->n, reinterpret_cast<uint32_t *>(&r->whole));
+        r->have_whole = st == E_SUCCESS;
+        r->rc = st;
+        return;
+    }
+    std::vector<uint32_t> coff((size_t)M + 1, 0u);
+    for (int j = 0; j < M; j++) coff[(size_t)j + 1] = coff[(size_t)j] + (uint32_t)batch[(size_t)j]->n;
+    const size_t total = coff[(size_t)M];
+    int st = e->input.reserve(total * rec) == hipSuccess ? E_SUCCESS : E_MEMORY_ERROR;
+    for (int j = 0; j < M && !st; j++)      // one H2D per call, back to back on the engine's stream
+        if (hipMemcpyAsync(static_cast<char *>(e->input.p) + (size_t)coff[(size_t)j] * rec, batch[(size_t)j]->in,
+                           batch[(size_t)j]->n * rec, hipMemcpyHostToDevice, e->stream) != hipSuccess) st = E_MEMORY_ERROR;
+    std::vector<Xyzz<F>> wins((size_t)M * kMsmBatchWindows);
+    std::vector<int> rc((size_t)M, E_MEMORY_ERROR);
+    if (st) e->failed = true;
+    else st = msm_batch_dispatch<F>(e, e->input.p, coff.data(), M, wins.data(), rc.data());
+    for (int j = 0; j < M; j++) {
+        MsmReq<F> *r = batch[(size_t)j];
+        r->rc = st ? st : rc[(size_t)j];
+        if (!r->rc) memcpy(r->wins, &wins[(size_t)j * kMsmBatchWindows], sizeof r->wins);
+    }
+}
+template <class F> static int msm_coalesced(byte *out, const byte *in, size_t n) {
+    Batcher<F> &b = batcher<F>();
+    MsmReq<F> req;
+    req.in = in;
+    req.n = n;
+    {
+        std::unique_lock<std::mutex> lk(b.mu);
+        b.pending.push_back(&req);
+        while (!req.done) {
+            if (!req.taken && b.in_flight < coalesce_flights(b.served + b.pending.size())) {
+                // lead: this request first, then the queue in arrival order, up to the batch limits
+                std::vector<MsmReq<F> *> batch{&req};
+                size_t total = req.n;
+                req.taken = true;
+                std::vector<MsmReq<F> *> rest;
+                for (MsmReq<F> *r : b.pending) {
+                    if (r == &req) continue;
+                    if ((int)batch.size() < kMsmBatchMaxCalls && total + r->n <= kCoalesceMaxRecords) { r->taken = true; batch.push_back(r); total += r->n; }
+                    else rest.push_back(r);
+                }
+                b.pending.swap(rest);
+                b.in_flight++;
+                b.served += batch.size();
+                lk.unlock();
+                g_co_batches++;
+                g_co_calls += batch.size();
+                for (uint64_t m = g_co_max.load(); batch.size() > m && !g_co_max.compare_exchange_weak(m, batch.size());) {}
+                run_msm_batch<F>(batch);
+                lk.lock();
+                b.in_flight--;
+                b.served -= batch.size();
+                for (MsmReq<F> *r : batch) r->done = true;
+                b.cv.notify_all();
+            } else {
+                b.cv.wait(lk);
+            }
+        }
+    }
+    if (req.rc) return req.rc;
+    Xyzz<F> acc;
+    if (req.have_whole) {
+        acc = req.whole;
+    } else {                            // Horner over the 32 window sums, highest window first
+        acc = xyzz_inf<F>();
+        for (int w = kMsmBatchWindows - 1; w >= 0; w--) {
+            for (int d = 0; d < kMsmBatchWindowBits; d++) acc = dbl(acc);
+            acc = add(acc, req.wins[w]);
+        }
+    }
+    host_encode_point<F>(out, to_affine(acc));
     return E_SUCCESS;
 }
 
@@ -458,6 +588,8 @@ template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_
     if (in_len == 0 || in_len % rec) return E_INVALID_LENGTH;      // before touching `in`
     const size_t n = in_len / rec;
     if (host_route(n, HostMax<F>::kUnits)) return device_present() ? msm_host_small<F>(out, in, n) : E_MEMORY_ERROR;
+    if (n >= CoalesceCfg<F>::kMinRecords && n <= CoalesceCfg<F>::kMaxRecords && coalesce_enabled() && g_window_override.load() == 0)
+        return msm_coalesced<F>(out, in, n);
     const std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
     if (pools.empty()) return msm_entry<F>(-1, out, in, n, false, false);
     const size_t shards = pools.size();
@@ -759,6 +891,11 @@ API size_t eip2537_hip_trim(size_t keep_bytes) {
         }
     g_cv.notify_all();
     return freed;
+}
+API void eip2537_hip_coalesce_stats(uint64_t *pipelines, uint64_t *calls, uint64_t *largest_batch) {
+    if (pipelines) *pipelines = g_co_batches.load();
+    if (calls) *calls = g_co_calls.load();
+    if (largest_batch) *largest_batch = g_co_max.load();
 }
 API int eip2537_hip_set_route(int route) {
     if (route < -1 || route > 1) return E_INVALID_LENGTH;

@@ -83,6 +83,14 @@ MsmPlan msm_make_plan(uint32_t n, int c_override, bool g2);
 int msm_g1_device(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override);
 int msm_g2_device(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override);
 
+// Coalesced batch of M small MSMs (every call below 2048 records; msm.hip "coalesced batch"): d_in holds
+// the calls' records back to back, coff[0..M] their record offsets (host).  Writes rc[j] and, per call,
+// kMsmBatchWindows XYZZ window sums (8-bit windows, lowest first) to wins_words; the caller applies
+// Horner.  Non-zero return: HIP failure, every call of the batch fails.
+static constexpr int kMsmBatchWindows = 32, kMsmBatchWindowBits = 8, kMsmBatchMaxCalls = 64;
+int msm_g1_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M, uint32_t *wins_words, int *rc);
+int msm_g2_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M, uint32_t *wins_words, int *rc);
+
 // Pairing: on success returns 0 and writes the product of the Miller loops (before the final
 // exponentiation) as 144 Montgomery words to `ml_words`.
 int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words);

@@ -820,6 +820,209 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     return E_SUCCESS;
 }
 
+// ---- coalesced batch of small MSMs ------------------------------------------------
+// M concurrent small calls (each below 2048 records, i.e. the c = 8 plan: 32 windows of 8 bits, 128
+// signed buckets, 256 in the unsigned top window) run as ONE pipeline over their concatenated records.
+// A (window, call) pair owns kBatchBmax = 256 consecutive bucket ids,
+//        bucket id = (window * M + call) * 256 + (bucket value - 1),
+// so for the counting sort, the task split and the accumulate the batch simply is one MSM whose windows
+// have M * 256 buckets (the kernels above run unchanged on that virtual plan); only the two ends know
+// about calls: the decode (record -> call by binary search over the call offsets, a first-error word
+// per call so that one bad call fails alone) and the reduce (one wave per (window, call): 16 four-lane
+// groups of 16 buckets, wavefront tree, no cross-call sums).  The host gets 32 window sums per call
+// and each caller finishes its own Horner / inversion / encoding on its own thread.
+static constexpr uint32_t kBatchBmax = 256;
+static constexpr int kBatchC = 8, kBatchW = 32;
+template <class F>
+__global__ void __launch_bounds__(256)
+k_msm_decode_batch(const uint32_t *__restrict__ in, MsmPlan real, uint32_t ntotal, const uint32_t *__restrict__ coff, int M,
+                   Aff<F> *__restrict__ pts, uint32_t *__restrict__ digits, unsigned long long *err) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= ntotal) return;
+    int lo = 0, hi = M;                                   // call j with coff[j] <= i < coff[j + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (coff[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t j = (uint32_t)lo;
+    bool live = false;
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords;
+    Aff<F> a;
+    const int st = decode_point<F>(a, w);
+    if (st != E_SUCCESS) {
+        atomicMin(&err[j], ((unsigned long long)(i - coff[j]) << 3) | (unsigned long long)st);
+    } else if (!is_inf(a)) {
+        pts[i] = a;
+        live = true;
+        decode_scalar(k, w + Wire<F>::kPointWords);
+    }
+    int wi = 0;
+    for_each_digit(k, real, [&](uint32_t g, uint32_t ng, bool nz) {
+        const uint32_t v = g - (uint32_t)wi * real.B + 1u;                // bucket value 1..nb_w of the call's own plan
+        digits[(size_t)wi * ntotal + i] = (live && nz) ? (((j * kBatchBmax + v) << 1) | ng) : 0u;
+        wi++;
+    });
+}
+// WPU waves per (window, call) unit: 16 * WPU four-lane groups of 16 / WPU buckets each, wavefront tree,
+// and for WPU = 4 an LDS step across the block's waves.  Small batches take WPU = 4 (a chain of 8
+// running-sum additions instead of 32) while their 128 * M waves still fit the chip in one round.
+template <class F, int WPU>
+__global__ void __launch_bounds__(256, 1)
+k_msm_reduce_batch(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, uint32_t units,
+                   Xyzz<F> *__restrict__ winout_) {
+    using T = typename AccumField<F>::T;
+    const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
+    Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
+    claim_whole_simd();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
+    const uint32_t unit = WPU == 4 ? blockIdx.x : blockIdx.x * 4u + (uint32_t)wave;
+    if (unit >= units) return;                                 // uniform in the wave (WPU = 4: in the block)
+    constexpr uint32_t S = kBatchBmax / (16u * WPU);
+    const uint32_t grp = (WPU == 4 ? (uint32_t)wave * 16u : 0u) + (uint32_t)(lane >> 2);
+    const uint32_t lo = grp * S, base = unit * kBatchBmax;
+    Xyzz<T> R = xyzz_inf<T>(), Q = xyzz_inf<T>();
+    for (uint32_t v = lo + S; v > lo; v--) {
+        const uint32_t g = base + v - 1u;
+        const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+        if (t1 > t0) R = add4(R, partial[t0], r, gb);          // multi-task buckets were folded into slot t0
+        Q = add4(Q, R, r, gb);
+    }
+    Xyzz<T> C = add4(Q, small_mul4(R, lo, r, gb), r, gb);      // sum_{v in (lo, lo + S]} v * B_v
+    for (int off = 4; off < 64; off <<= 1) {
+        Xyzz<T> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 4) C = add4(C, o, r, gb);
+    }
+    if (WPU == 4) {
+        __shared__ Xyzz<T> sm[4];
+        if (lane == 0) sm[wave] = C;
+        __syncthreads();
+        if (wave == 0 && lane < 4) {
+            for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
+            if (lane == 0) winout[unit] = C;
+        }
+    } else if (lane == 0) {
+        winout[unit] = C;
+    }
+}
+
+// d_in: the M calls' records back to back in HBM; coff[0..M]: record offsets of the calls (host memory).
+// Writes rc[j] (0 or the EIP2537 code of call j's lowest bad record) and, for the good calls, their
+// kBatchW window sums to wins[j * kBatchW ...].  Returns non-zero only for a HIP failure (every call fails).
+template <class F>
+static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff, int M, Xyzz<F> *wins, int *rc) {
+    const size_t n = coff[M];
+    if (M < 1 || M > 256 || n == 0 || n >= (1ull << 24)) return E_MEMORY_ERROR;
+    MsmPlan real = msm_make_plan(1024, kBatchC, ReduceCfg<F>::kFourLane);          // the plan every call below 2048 records has
+    if (real.c != kBatchC || real.W != kBatchW || real.B != 128u || real.BT != kBatchBmax) return E_MEMORY_ERROR;
+    MsmPlan pl = real;                                        // the virtual plan of the whole batch
+    pl.n = (uint32_t)n;
+    pl.B = pl.BT = (uint32_t)M * kBatchBmax;
+    pl.NB = (uint32_t)pl.W * pl.B;
+    pl.max_entries = (uint64_t)n * pl.W;
+    const uint32_t lshift = kMinTaskShift;                    // tasks of <= 16 entries: these plans are chain-bound
+    const uint32_t gshift = 0;
+    pl.L = 1u << lshift;
+    pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
+    const uint32_t units = (uint32_t)pl.W * (uint32_t)M;
+    const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
+    const uint32_t nbmax = pl.B;
+    if (nbmax > 2u * kLdsWords) return E_MEMORY_ERROR;         // LDS histogram: 65536 packed counters
+    HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
+    HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
+    HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
+    HIPCHK(e->digits.reserve((size_t)pl.W * n * 4));
+    HIPCHK(e->hist16.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));
+    HIPCHK(e->slice_base.reserve((size_t)pl.W * nslices * nbmax * 4));
+    HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
+    HIPCHK(e->entries.reserve(pl.max_entries * 4));
+    HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
+    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
+    HIPCHK(e->winout.reserve((size_t)units * sizeof(Xyzz<F>)));
+    HIPCHK(e->misc.reserve(64 + (size_t)(M + 1) * 4 + (size_t)M * 8));
+    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + 2 * 65 * 4));
+    HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
+    HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));
+    if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
+
+    hipStream_t s = e->stream;
+    auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
+    auto *err = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->misc.p) + 64);        // [M]
+    auto *d_coff = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 64 + (size_t)M * 8);   // [M + 1]
+    HIPCHK(hipMemsetAsync(err, 0xFF, (size_t)M * 8, s));
+    HIPCHK(hipMemsetAsync(totals, 0, 16, s));
+    HIPCHK(hipMemcpyAsync(d_coff, coff, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
+    auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
+    auto *digits = reinterpret_cast<uint32_t *>(e->digits.p);
+    auto *counts = reinterpret_cast<uint32_t *>(e->counts.p);
+    auto *offsets = reinterpret_cast<uint32_t *>(e->offsets.p);
+    auto *hist16 = reinterpret_cast<uint32_t *>(e->hist16.p);
+    auto *base = reinterpret_cast<uint32_t *>(e->slice_base.p);
+    auto *taskoff = reinterpret_cast<uint32_t *>(e->taskoff.p);
+    auto *entries = reinterpret_cast<uint32_t *>(e->entries.p);
+    auto *tasks = reinterpret_cast<Task *>(e->tasks.p);
+    auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
+    auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
+    auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
+    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
+    auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
+    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
+    {
+        LastPlan lp{};
+        snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2<%s>", ReduceCfg<F>::kName);
+        lp.c = pl.c; lp.windows = pl.W; lp.lanes = 2; lp.units = (uint32_t)n; lp.buckets = pl.NB;
+        e->last_plan = lp;
+    }
+    HIPCHK(hipEventRecord(e->ev_start, s));
+    hipLaunchKernelGGL(k_msm_decode_batch<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, real, (uint32_t)n, d_coff, M, pts, digits, err);
+    hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);
+    hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
+    const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;
+    HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));
+    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
+    hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries);
+    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
+                       split_small, split_big, totals + 2);
+    const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
+    hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist, gshift);
+    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
+    HIPCHK(hipEventRecord(e->ev_a, s));
+    hipLaunchKernelGGL(k_msm_accum2<F>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    HIPCHK(hipEventRecord(e->ev_b, s));
+    hipLaunchKernelGGL(k_msm_fold_small4<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
+    hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
+    if (units * 4u <= 1024u)       // one block per unit while 4 waves per unit fit one round of one wave per SIMD
+        hipLaunchKernelGGL((k_msm_reduce_batch<F, 4>), dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
+    else
+        hipLaunchKernelGGL((k_msm_reduce_batch<F, 1>), dim3((units + 3u) / 4u), dim3(256), 0, s, partial, taskoff, units, winout);
+    HIPCHK(hipEventRecord(e->ev_stop, s));
+    HIPCHK(hipGetLastError());
+
+    std::vector<unsigned long long> herr((size_t)M);
+    std::vector<Xyzz<F>> hw(units);
+    HIPCHK(hipMemcpyAsync(herr.data(), err, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hw.data(), winout, (size_t)units * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
+    for (int j = 0; j < M; j++) {
+        rc[j] = herr[(size_t)j] != ~0ull ? (int)(herr[(size_t)j] & 7ull) : E_SUCCESS;
+        for (int w = 0; w < kBatchW; w++) wins[(size_t)j * kBatchW + w] = hw[(size_t)w * (uint32_t)M + (uint32_t)j];
+    }
+    return E_SUCCESS;
+}
+int msm_g1_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M, uint32_t *wins_words, int *rc) {
+    return msm_batch_device_t<Fp>(e, d_in, coff, M, reinterpret_cast<Xyzz<Fp> *>(wins_words), rc);
+}
+int msm_g2_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M, uint32_t *wins_words, int *rc) {
+    return msm_batch_device_t<Fp2>(e, d_in, coff, M, reinterpret_cast<Xyzz<Fp2> *>(wins_words), rc);
+}
+
 int msm_g1_device(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
     return msm_device_t<Fp>(e, d_in, n, partial_words, c_override);
 }

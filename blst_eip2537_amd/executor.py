@@ -88,6 +88,8 @@ def lib():
         f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     L.eip2537_hip_init.restype = ctypes.c_int
     L.eip2537_hip_init.argtypes = [ctypes.c_int]
+    L.eip2537_hip_coalesce_stats.restype = None
+    L.eip2537_hip_coalesce_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 3
     L.eip2537_hip_set_route.restype = ctypes.c_int
     L.eip2537_hip_set_route.argtypes = [ctypes.c_int]
     L.eip2537_hip_set_window.restype = ctypes.c_int
@@ -229,6 +231,13 @@ class Eip2537Executor:
     @staticmethod
     def trim(keep_bytes=0):
         return int(lib().eip2537_hip_trim(keep_bytes))
+
+    @staticmethod
+    def coalesce_stats():
+        """(device pipelines run for small multiexp calls, calls served, largest batch) since load."""
+        a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        lib().eip2537_hip_coalesce_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return a.value, b.value, c.value
 
     @staticmethod
     def set_route(route):

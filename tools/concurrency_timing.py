@@ -20,7 +20,7 @@ from blst_eip2537_amd import Eip2537Executor  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--threads", type=int, nargs="*", default=[1, 2, 4, 8, 16])
+    ap.add_argument("--threads", type=int, nargs="*", default=[1, 2, 4, 8, 16, 32, 64])
     ap.add_argument("--calls", type=int, default=40)
     args = ap.parse_args()
     ex = Eip2537Executor()
@@ -32,7 +32,7 @@ def main():
         "pairing_16": ("pairing", ex.gen_pairing_input(16, 3, 5, 7, 11)),
     }
     slots = os.environ.get("EIP2537_HIP_SLOTS", "8 (default)")
-    print("slots=%s" % slots)
+    print("slots=%s coalesce=%s" % (slots, os.environ.get("EIP2537_HIP_COALESCE", "1 (default)")))
     for name, (fn, inp) in work.items():
         want = getattr(ex, fn)(inp)           # warm-up, and the value every thread must reproduce
         for _ in range(8):
@@ -65,6 +65,7 @@ def main():
             assert not bad, "result mismatch under concurrency"
             row.append("T=%d %7.0f calls/s" % (t, t * args.calls / dt))
         print("%-12s %s" % (name, "  ".join(row)))
+    print("coalesce stats (device pipelines, calls, largest batch): %s" % (ex.coalesce_stats(),))
 
 
 if __name__ == "__main__":
