@@ -19,10 +19,16 @@
 typedef unsigned char byte;
 enum { SHIM_MEMORY_ERROR = 7 };
 
-static void *volatile g_handle;
+typedef int (*precompile_fn)(byte *, const byte *, size_t);
+
+/* The engine handle and every resolved entry point are published with release / acquire atomics:
+ * callers are concurrent (cargo test threads, goroutines) and the first calls race.  Two threads may
+ * both dlopen / dlsym -- the loader reference-counts the handle and both get the same addresses --
+ * after which every call is one atomic load and an indirect call (no dlsym on the hot path). */
+static void *g_handle;
 
 static void *shim_handle(void) {
-    void *h = g_handle;
+    void *h = __atomic_load_n(&g_handle, __ATOMIC_ACQUIRE);
     if (h) return h;
     const char *path = getenv("EIP2537_HIP_LIB");
     h = dlopen(path && *path ? path : "libeip2537_hip.so", RTLD_NOW | RTLD_LOCAL);
@@ -30,25 +36,28 @@ static void *shim_handle(void) {
         fprintf(stderr, "[eip2537 shim] cannot load the HIP engine: %s (set EIP2537_HIP_LIB)\n", dlerror());
         return NULL;
     }
-    /* benign race: two threads may both dlopen; the loader reference-counts the handle */
-    g_handle = h;
+    __atomic_store_n(&g_handle, h, __ATOMIC_RELEASE);
     return h;
 }
 
-typedef int (*precompile_fn)(byte *, const byte *, size_t);
-static int shim_forward(const char *name, byte *out, const byte *in, size_t len) {
-    void *h = shim_handle();
-    if (!h) return SHIM_MEMORY_ERROR;
-    precompile_fn f = (precompile_fn)dlsym(h, name);
+static int shim_forward(precompile_fn *slot, const char *name, byte *out, const byte *in, size_t len) {
+    precompile_fn f = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
     if (!f) {
-        fprintf(stderr, "[eip2537 shim] engine lacks symbol %s\n", name);
-        return SHIM_MEMORY_ERROR;
+        void *h = shim_handle();
+        if (!h) return SHIM_MEMORY_ERROR;
+        f = (precompile_fn)dlsym(h, name);
+        if (!f) {
+            fprintf(stderr, "[eip2537 shim] engine lacks symbol %s\n", name);
+            return SHIM_MEMORY_ERROR;
+        }
+        __atomic_store_n(slot, f, __ATOMIC_RELEASE);
     }
     return f(out, in, len);
 }
 
-#define FORWARD(name) \
-    int name(byte *out, const byte *in, size_t in_len) { return shim_forward(#name, out, in, in_len); }
+#define FORWARD(name)                                                                         \
+    static precompile_fn shim_fn_##name;                                                      \
+    int name(byte *out, const byte *in, size_t in_len) { return shim_forward(&shim_fn_##name, #name, out, in, in_len); }
 
 FORWARD(bls12_g1add)
 FORWARD(bls12_g1mul)
