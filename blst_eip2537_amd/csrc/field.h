@@ -296,6 +296,48 @@ inline Fp fp_mul_limbs64(const Fp &a, const Fp &b) {
 }
 #endif
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && defined(__ADX__) && defined(__BMI2__) && !defined(EIP_HOST_NO_ASM)
+#define EIP_HOST_ADX 1
+// Host Montgomery product with the two independent carry chains of ADX (adcx: low halves, adox: high
+// halves) over mulx rows -- the same CIOS schedule as fp_mul_limbs64 above, which compilers serialise
+// on one carry flag (51 ns per product on the GPU box's host against ~30 ns here).  Per outer step:
+// t += a * b_i, m = t0 * n0, t += m * p, and the limb names rotate by one (t0 has become zero and
+// serves as the next step's top limb), so there is no shifting at all.  Everything stays below 2p + 1
+// ulp, hence in 6 limbs + the rotating zero; the final conditional subtraction is hostfp::reduce_once.
+// Host-side products are the serial tails of the engine: the window Horner of an MSM, the 63-squaring
+// Horner and the final exponentiation of a pairing check, the single-pair precompiles and the
+// small-call route (api.hip).
+#define EIP_ADX_ROW(src, T0, T1, T2, T3, T4, T5, T6)                                             \
+    "xorl %k[z], %k[z]\n\t"                                                                      \
+    "mulxq 0(%[" src "]), %[lo], %[hi]\n\t adcxq %[lo], %[" T0 "]\n\t adoxq %[hi], %[" T1 "]\n\t"  \
+    "mulxq 8(%[" src "]), %[lo], %[hi]\n\t adcxq %[lo], %[" T1 "]\n\t adoxq %[hi], %[" T2 "]\n\t"  \
+    "mulxq 16(%[" src "]), %[lo], %[hi]\n\t adcxq %[lo], %[" T2 "]\n\t adoxq %[hi], %[" T3 "]\n\t" \
+    "mulxq 24(%[" src "]), %[lo], %[hi]\n\t adcxq %[lo], %[" T3 "]\n\t adoxq %[hi], %[" T4 "]\n\t" \
+    "mulxq 32(%[" src "]), %[lo], %[hi]\n\t adcxq %[lo], %[" T4 "]\n\t adoxq %[hi], %[" T5 "]\n\t" \
+    "mulxq 40(%[" src "]), %[lo], %[hi]\n\t adcxq %[lo], %[" T5 "]\n\t adoxq %[hi], %[" T6 "]\n\t" \
+    "adcxq %[z], %[" T6 "]\n\t"
+#define EIP_ADX_STEP(off, T0, T1, T2, T3, T4, T5, T6)                                            \
+    "movq " off "(%[b]), %%rdx\n\t" EIP_ADX_ROW("a", T0, T1, T2, T3, T4, T5, T6)                   \
+    "movq %[" T0 "], %%rdx\n\t imulq %[n0], %%rdx\n\t" EIP_ADX_ROW("p", T0, T1, T2, T3, T4, T5, T6)
+inline Fp fp_mul_adx(const Fp &a, const Fp &b) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, lo, hi, z;
+    const uint64_t n0 = K_N0_64;
+    __asm__(EIP_ADX_STEP("0", "t0", "t1", "t2", "t3", "t4", "t5", "t6")
+            EIP_ADX_STEP("8", "t1", "t2", "t3", "t4", "t5", "t6", "t0")
+            EIP_ADX_STEP("16", "t2", "t3", "t4", "t5", "t6", "t0", "t1")
+            EIP_ADX_STEP("24", "t3", "t4", "t5", "t6", "t0", "t1", "t2")
+            EIP_ADX_STEP("32", "t4", "t5", "t6", "t0", "t1", "t2", "t3")
+            EIP_ADX_STEP("40", "t5", "t6", "t0", "t1", "t2", "t3", "t4")
+            : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [t4] "+&r"(t4), [t5] "+&r"(t5), [t6] "+&r"(t6),
+              [lo] "=&r"(lo), [hi] "=&r"(hi), [z] "=&r"(z)
+            : [a] "r"(a.l), [b] "r"(b.l), [p] "r"(hostfp::kP64), [n0] "rm"(n0)
+            : "rdx", "cc", "memory");
+    // after six rotations the value sits in t6, t0, t1, t2, t3, t4 (t5 is the spent zero)
+    hostfp::L6 r{{t6, t0, t1, t2, t3, t4}};
+    return hostfp::store(hostfp::reduce_once(r));
+}
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(EIP_DEBUG_OLD_MUL)
 static __device__ __noinline__ Fp fp_mul_outlined(Fp a, Fp b) { return fp_mul_limbs32(a, b); }
@@ -306,18 +348,27 @@ static __device__ __noinline__ Fp fp_sqr_outlined(Fp a) { return fp_sqr_cols28(a
 #endif
 #endif
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline Fp fp_mul_host(const Fp &a, const Fp &b) {
+#if defined(EIP_HOST_ADX)
+    return fp_mul_adx(a, b);
+#else
+    return fp_mul_limbs64(a, b);
+#endif
+}
+#endif
 HD Fp mul(const Fp &a, const Fp &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return fp_mul_outlined(a, b);
 #else
-    return fp_mul_limbs64(a, b);
+    return fp_mul_host(a, b);
 #endif
 }
 HD Fp sqr(const Fp &a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return fp_sqr_outlined(a);
 #else
-    return fp_mul_limbs64(a, a);
+    return fp_mul_host(a, a);
 #endif
 }
 
@@ -356,7 +407,7 @@ HD Fp fp_mul_leaf(const Fp &a, const Fp &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return fp_mul_cols28(a, b);
 #else
-    return fp_mul_limbs64(a, b);
+    return fp_mul_host(a, b);
 #endif
 }
 HD Fp2 fp2_mul_body(const Fp2 &a, const Fp2 &b) {
@@ -427,14 +478,14 @@ HD FpI mul(const FpI &a, const FpI &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return FpI{fp_mul_cols28(a.v, b.v)};
 #else
-    return FpI{fp_mul_limbs64(a.v, b.v)};
+    return FpI{fp_mul_host(a.v, b.v)};
 #endif
 }
 HD FpI sqr(const FpI &a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return FpI{fp_sqr_cols28(a.v)};
 #else
-    return FpI{fp_mul_limbs64(a.v, a.v)};
+    return FpI{fp_mul_host(a.v, a.v)};
 #endif
 }
 

@@ -53,7 +53,7 @@ int main(int argc, char **argv) {
     if (argc < 4) return 2;
     int threads = atoi(argv[1]);
     reps = atoi(argv[2]);
-    static char line[1 << 22];
+    static char line[(1 << 25) + 16];      /* a 2^16-record input is 21 MB of hex */
     for (int a = 3; a < argc && ncases < 64; a++) {
         FILE *f = fopen(argv[a], "r");
         if (!f) { perror(argv[a]); return 2; }

@@ -57,7 +57,8 @@ def test_concurrent_small_g1_calls_are_coalesced_and_exact(X, clib):
     before = X.coalesce_stats()
     assert _hammer(jobs) == []
     pipelines, calls, largest = (b - a for a, b in zip(before, X.coalesce_stats()))
-    assert calls == 3 * len(jobs)
+    queued = sum(1 for _, inp, _ in jobs if 3 <= len(inp) // 160 <= 512)        # below: the host crossover; above: straight to an engine
+    assert calls == 3 * queued
     assert pipelines < calls, "no call ever shared a pipeline"
     assert X.coalesce_stats()[2] >= 2
 
