@@ -331,6 +331,131 @@ __device__ __forceinline__ void pair_walk(const Aff<Fp2> *__restrict__ qmont, co
     if (!g2_membership_lanes(T, Q, prod) && sl == 0)
         atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
+// ---- 8 lanes per pair, split by Fp2 component ---------------------------------------------------
+// In the replicated form above every lane holds whole Fp2 values and repeats every linear step on both
+// components: a doubling step was ~8 200 instructions of which 2 350 multiply-adds, ~1 800 carry-chain
+// additions / subtractions plus 830 hazard nops, and the running values did not fit the registers
+// (1 GB of scratch stores per launch at 2^12 pairs).  Here lane (p, q) of the pair's group holds only
+// COMPONENT q of every Fp2 value (replicated over the four lane pairs p): the linear steps of both steps
+// are component-wise, so they run on Fp -- half the instructions, half the registers -- and only a
+// product needs the partner lane's component of its two operands (one exchange with lane ^ 1).
+// Lane pair p computes product p of a round by the schoolbook rule, as before.
+#ifndef EIP_WALK8_SPLIT
+#define EIP_WALK8_SPLIT 1
+#endif
+struct TcFp { Fp x, y, z; };                      // this lane's component of the running point
+struct Prod4c { Fp r0, r1, r2, r3; };             // this lane's component of the four products of a round
+struct Walk8c {
+    int p, q, lane, gbase;
+    __device__ __forceinline__ Walk8c(int lane_, int sl, int gb) : p(sl >> 1), q(sl & 1), lane(lane_), gbase(gb) {}
+    __device__ __forceinline__ Prod4c operator()(const Fp &a0, const Fp &a1, const Fp &a2, const Fp &a3,
+                                                 const Fp &b0, const Fp &b1, const Fp &b2, const Fp &b3) const {
+        const Fp u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);      // own components of this pair's operands
+        const Fp up = shfl_from(u, lane ^ 1), vp = shfl_from(v, lane ^ 1);      // the partner's
+        // q = 0: c0 = u0 v0 - u1 v1      q = 1: c1 = u0 v1 + u1 v0
+        const Fp m1 = fp_mul_cols28(sel2(q, u, up), v), m2 = fp_mul_cols28(sel2(q, up, u), vp);
+        const Fp c = q ? add(m1, m2) : sub(m1, m2);
+        return Prod4c{shfl_from(c, gbase + q), shfl_from(c, gbase + 2 + q), shfl_from(c, gbase + 4 + q), shfl_from(c, gbase + 6 + q)};
+    }
+};
+// lane pair `part` stores line coefficient `part` (a0, a1, a4), each lane its component
+__device__ __forceinline__ void store_line_part_c(LineRec *dst, int part, const Fp &v, bool contributes, const Walk8c &w) {
+    if (w.p == part) {
+        Fp *slot = reinterpret_cast<Fp *>(&dst->a0) + 2 * part + w.q;
+        *slot = contributes ? v : ((part == 0 && w.q == 0) ? fp_one() : fp_zero());
+    }
+}
+__device__ __forceinline__ void miller_dbl_step_c(TcFp &T, const Walk8c &prod, LineRec *dst, bool contributes) {
+    Prod4c pr = prod(T.x, T.y, T.z, T.y, T.x, T.y, T.z, T.z);
+    const Fp A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
+    const Fp E = add(dbl(A), A), XB = add(T.x, B);
+    pr = prod(B, XB, E, E, B, XB, E, T.x);
+    const Fp C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
+    store_line_part_c(dst, 0, sub(EX, dbl(B)), contributes, prod);              // 3X^3 - 2Y^2
+    const Fp D = dbl(sub(sub(t, A), C));
+    const Fp X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
+    const Fp C8 = dbl(dbl(dbl(C)));
+    pr = prod(E, Z3, E, E, ZZ, ZZ, sub(D, X3), ZZ);
+    store_line_part_c(dst, 1, neg(pr.r0), contributes, prod);                   // -3X^2 Z^2
+    store_line_part_c(dst, 2, pr.r1, contributes, prod);                        // 2YZ^3
+    T.x = X3;
+    T.y = sub(pr.r2, C8);
+    T.z = Z3;
+}
+__device__ __forceinline__ void miller_add_step_c(TcFp &T, const Fp &Qx, const Fp &Qy, const Walk8c &prod, LineRec *dst, bool contributes) {
+    Prod4c pr = prod(T.z, T.z, T.z, T.z, T.z, T.z, T.z, T.z);
+    const Fp ZZ = pr.r0;
+    pr = prod(Qx, ZZ, Qx, Qx, ZZ, T.z, ZZ, ZZ);
+    const Fp U2 = pr.r0, ZZZ = pr.r1;
+    pr = prod(Qy, Qy, Qy, Qy, ZZZ, ZZZ, ZZZ, ZZZ);
+    const Fp S2 = pr.r0;
+    const Fp H = sub(U2, T.x), th = sub(S2, T.y);
+    pr = prod(H, T.z, th, th, H, H, th, Qx);
+    const Fp HH = pr.r0, Z3 = pr.r1, TH2 = pr.r2, thQx = pr.r3;
+    pr = prod(HH, T.x, Z3, HH, H, HH, Qy, H);
+    const Fp HHH = pr.r0, V = pr.r1, Z3Qy = pr.r2;
+    const Fp X3 = sub(sub(TH2, HHH), dbl(V));
+    const Fp VX = sub(V, X3);
+    pr = prod(th, T.y, th, th, VX, HHH, VX, VX);
+    store_line_part_c(dst, 0, sub(thQx, Z3Qy), contributes, prod);
+    store_line_part_c(dst, 1, neg(th), contributes, prod);
+    store_line_part_c(dst, 2, Z3, contributes, prod);
+    T.x = X3;
+    T.y = sub(pr.r0, pr.r1);
+    T.z = Z3;
+}
+__device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP,
+                                            const uint8_t *__restrict__ flagQ, uint32_t k, LineRec *__restrict__ lines,
+                                            unsigned long long *err, Aff<Fp2> *sQ) {
+    const int lane = threadIdx.x & 63, sl = lane & 7, gbase = lane & ~7, gi = lane >> 3, q = sl & 1;
+    const uint32_t i = blockIdx.x * 8u + (uint32_t)gi;
+    bool q_live = false, contributes = false;
+    TcFp T;
+    claim_whole_simd();
+    if (i < k) {                              // uniform within a lane group
+        q_live = flagQ[i] != 0;
+        contributes = q_live && flagP[i] != 0;                   // else the pair contributes 1
+        const Aff<Fp2> Q = qmont[i];
+        if (sl == 0) sQ[gi] = Q;
+        T = TcFp{sel2(q, Q.x.c0, Q.x.c1), sel2(q, Q.y.c0, Q.y.c1), q ? fp_zero() : fp_one()};
+    }
+    __syncthreads();
+    if (i >= k) return;
+    if (!q_live) {                            // Q at infinity (or undecodable: reported by the decode)
+        if (sl < 3) {
+            const Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
+            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[sl] = v;
+        }
+        return;
+    }
+    const Walk8c prod(lane, sl, gbase);
+    const uint64_t z = K_Z_ABS;
+    int s = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        miller_dbl_step_c(T, prod, &lines[(size_t)s * k + i], contributes);
+        s++;
+        if ((z >> bit) & 1ull) {              // 5 of 63 steps
+            const Fp Qx = q ? sQ[gi].x.c1 : sQ[gi].x.c0, Qy = q ? sQ[gi].y.c1 : sQ[gi].y.c0;
+            miller_add_step_c(T, Qx, Qy, prod, &lines[(size_t)s * k + i], contributes);
+            s++;
+        }
+    }
+    // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T:  psi(Q).x Z^2 == X  and  -psi(Q).y Z^3 == Y
+    const Fp Qx = q ? sQ[gi].x.c1 : sQ[gi].x.c0, Qy = q ? sQ[gi].y.c1 : sQ[gi].y.c0;
+    const Fp cx = q ? neg(Qx) : Qx, cy = q ? neg(Qy) : Qy;                      // conj: component 1 negated
+    const Fp kx = q ? Fp{{K_PSI_X_C1}} : Fp{{K_PSI_X_C0}}, ky = q ? Fp{{K_PSI_Y_C1}} : Fp{{K_PSI_Y_C0}};
+    Prod4c pr = prod(cx, cy, T.z, cx, kx, ky, T.z, kx);
+    const Fp px = pr.r0, py = neg(pr.r1), zz = pr.r2;
+    pr = prod(px, zz, px, px, zz, T.z, zz, zz);
+    const Fp lhs_x = pr.r0, zzz = pr.r1;
+    pr = prod(py, py, py, py, zzz, zzz, zzz, zzz);
+    int same = (eq(lhs_x, T.x) && eq(pr.r0, T.y)) ? 1 : 0, zzero = is_zero(T.z) ? 1 : 0;
+    same &= __shfl(same, lane ^ 1, 64);                                         // both components
+    zzero &= __shfl(zzero, lane ^ 1, 64);
+    if ((!same || zzero) && sl == 0)
+        atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+}
+
 __global__ void __launch_bounds__(64)
 k_pair_lines4(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
@@ -341,7 +466,11 @@ __global__ void __launch_bounds__(64)
 k_pair_lines8(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
     __shared__ Aff<Fp2> sQ[8];
+#if EIP_WALK8_SPLIT
+    pair_walk8c(qmont, flagP, flagQ, k, lines, err, sQ);
+#else
     pair_walk<8>(qmont, flagP, flagQ, k, lines, err, sQ);
+#endif
 }
 __global__ void __launch_bounds__(64)
 k_pair_lines16(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,

@@ -17,12 +17,13 @@ struct kase { fn_t fn; int want_code; size_t in_len, out_len; byte *in, *want; c
 static struct kase cases[64];
 static int ncases, reps;
 
+static unsigned nib(char c) { return c <= '9' ? (unsigned)(c - '0') : (unsigned)((c | 32) - 'a' + 10); }
 static size_t unhex(const char *s, byte **out) {
     size_t n = strlen(s);
     while (n && (s[n - 1] == '\n' || s[n - 1] == '\r')) n--;
     if (n == 1 && s[0] == '-') { *out = NULL; return 0; }
     *out = malloc(n / 2 + 1);
-    for (size_t i = 0; i < n / 2; i++) { unsigned v; sscanf(s + 2 * i, "%2x", &v); (*out)[i] = (byte)v; }
+    for (size_t i = 0; i < n / 2; i++) (*out)[i] = (byte)((nib(s[2 * i]) << 4) | nib(s[2 * i + 1]));
     return n / 2;
 }
 static fn_t lookup(const char *op) {
