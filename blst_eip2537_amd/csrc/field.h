@@ -165,7 +165,7 @@ HD Fp fp_mul_limbs32(const Fp &a, const Fp &b) {
 // more than half of its instructions on carry plumbing; measured 1.9x slower, profiles/).
 // Reduction removes 13 x 28 + 20 = 384 bits, so R stays 2^384 and the result is bit-identical
 // to the host's 6 x 64-bit product.
-HD Fp fp_mul_cols28(const Fp &a, const Fp &b) {
+template <bool REDUCE> HD Fp fp_mul_cols28_t(const Fp &a, const Fp &b) {
     const uint32_t p28[14] = {K_P28};
     const uint32_t M28 = 0x0fffffffu;
     uint32_t al[14], bl[14];
@@ -207,10 +207,13 @@ HD Fp fp_mul_cols28(const Fp &a, const Fp &b) {
         uint64_t t = (uint64_t)d[q] | ((uint64_t)d[q + 1] << 28) | ((uint64_t)(q + 2 < 16 ? d[q + 2] : 0u) << 56);
         r.l[w] = (uint32_t)(t >> o);
     }
-    return fp_reduce_once(r);
+    return REDUCE ? fp_reduce_once(r) : r;
 }
+// Canonical result in [0, p).
+HD Fp fp_mul_cols28(const Fp &a, const Fp &b) { return fp_mul_cols28_t<true>(a, b); }
+
 // Squaring: the 91 cross products are computed once against a doubled operand.
-HD Fp fp_sqr_cols28(const Fp &a) {
+template <bool REDUCE> HD Fp fp_sqr_cols28_t(const Fp &a) {
     const uint32_t p28[14] = {K_P28};
     const uint32_t M28 = 0x0fffffffu;
     uint32_t al[14], a2[14];
@@ -254,8 +257,10 @@ HD Fp fp_sqr_cols28(const Fp &a) {
         uint64_t t = (uint64_t)d[q] | ((uint64_t)d[q + 1] << 28) | ((uint64_t)(q + 2 < 16 ? d[q + 2] : 0u) << 56);
         r.l[w] = (uint32_t)(t >> o);
     }
-    return fp_reduce_once(r);
+    return REDUCE ? fp_reduce_once(r) : r;
 }
+HD Fp fp_sqr_cols28(const Fp &a) { return fp_sqr_cols28_t<true>(a); }
+
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host: the same 48 bytes as 6 x 64-bit limbs.  Operand scanning with whole rows of 64x64->128
@@ -464,30 +469,76 @@ HD Fp2 inv(const Fp2 &a) {
 }
 
 
-// FpI: the same 48 bytes as Fp, but its product and square are inlined at every use.  Used only
-// by k_msm_accum<Fp>, the dominant kernel, where one mixed addition (8M + 2S) is the whole loop
-// body and the call / argument-shuffle overhead of the out-of-line product is measurable.
+// FpI: the same 48 bytes as Fp, with two differences that matter only to the kernels that are bound by
+// the instruction count of their field arithmetic (k_msm_accum<Fp>, the G1 fold / reduce kernels):
+//  * its product and square are inlined at every use (the call / argument-shuffle overhead of the
+//    out-of-line product is measurable when one mixed addition is the whole loop body), and
+//  * on the device its values are only kept in [0, 2p), not [0, p): the Montgomery product of two such
+//    values is below (4p^2 + R p) / R < 1.41 p (R = 2^384 > 9.8 p), so the product needs NO final
+//    conditional subtraction (36 instructions + 24 hazard nops of ~620), and addition / subtraction
+//    wrap at 2p for the same price as they wrapped at p.  Zero is {0, p}.  Canonical Fp values are valid
+//    FpI values (decoded points go in as they are); values leave through fp_canon().
 struct FpI { Fp v; };
+HD Fp fp_2p() {
+    const Fp p = fp_p();
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = (p.l[i] << 1) | (i ? p.l[i - 1] >> 31 : 0u);
+    return r;
+}
+HD Fp fp_canon(const FpI &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_reduce_once(a.v);
+#else
+    return a.v;
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+HD bool is_zero(const FpI &a) {
+    const Fp p = fp_p();
+    uint32_t z = 0, zp = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { z |= a.v.l[i]; zp |= a.v.l[i] ^ p.l[i]; }
+    return z == 0 || zp == 0;
+}
+HD FpI add(const FpI &a, const FpI &b) {
+    const Fp m = fp_2p();
+    Fp t, d;
+    unsigned c = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) t.l[i] = __builtin_addc(a.v.l[i], b.v.l[i], c, &c);          // < 4p < 2^384
+#pragma unroll
+    for (int i = 0; i < 12; i++) d.l[i] = __builtin_subc(t.l[i], m.l[i], borrow, &borrow);
+    FpI r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v.l[i] = borrow ? t.l[i] : d.l[i];
+    return r;
+}
+HD FpI sub(const FpI &a, const FpI &b) {
+    const Fp m = fp_2p();
+    Fp d, e;
+    unsigned borrow = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) d.l[i] = __builtin_subc(a.v.l[i], b.v.l[i], borrow, &borrow);
+#pragma unroll
+    for (int i = 0; i < 12; i++) e.l[i] = __builtin_addc(d.l[i], m.l[i], c, &c);
+    FpI r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v.l[i] = borrow ? e.l[i] : d.l[i];
+    return r;
+}
+HD FpI mul(const FpI &a, const FpI &b) { return FpI{fp_mul_cols28_t<false>(a.v, b.v)}; }
+HD FpI sqr(const FpI &a) { return FpI{fp_sqr_cols28_t<false>(a.v)}; }
+#else       // the host pass only parses the kernels that use FpI
 HD bool is_zero(const FpI &a) { return is_zero(a.v); }
-HD bool eq(const FpI &a, const FpI &b) { return eq(a.v, b.v); }
 HD FpI add(const FpI &a, const FpI &b) { return FpI{add(a.v, b.v)}; }
 HD FpI sub(const FpI &a, const FpI &b) { return FpI{sub(a.v, b.v)}; }
-HD FpI neg(const FpI &a) { return FpI{neg(a.v)}; }
-HD FpI dbl(const FpI &a) { return FpI{dbl(a.v)}; }
-HD FpI mul(const FpI &a, const FpI &b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return FpI{fp_mul_cols28(a.v, b.v)};
-#else
-    return FpI{fp_mul_host(a.v, b.v)};
+HD FpI mul(const FpI &a, const FpI &b) { return FpI{fp_mul_host(a.v, b.v)}; }
+HD FpI sqr(const FpI &a) { return FpI{fp_mul_host(a.v, a.v)}; }
 #endif
-}
-HD FpI sqr(const FpI &a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return FpI{fp_sqr_cols28(a.v)};
-#else
-    return FpI{fp_mul_host(a.v, a.v)};
-#endif
-}
+HD bool eq(const FpI &a, const FpI &b) { return is_zero(sub(a, b)); }
+HD FpI neg(const FpI &a) { return sub(FpI{fp_zero()}, a); }
+HD FpI dbl(const FpI &a) { return add(a, a); }
 
 // uniform spelling for the curve templates
 template <class F> HD F f_zero();

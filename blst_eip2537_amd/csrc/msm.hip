@@ -404,6 +404,14 @@ k_msm_accum2(const Aff<F> *__restrict__ pts, const uint32_t *__restrict__ entrie
 // field type the accumulate loop computes in: Fp -> FpI (inlined products), Fp2 unchanged
 template <class F> struct AccumField { using T = F; };
 template <> struct AccumField<Fp> { using T = FpI; };
+// FpI values live in [0, 2p) (field.h): whatever leaves the device for the host's canonical arithmetic
+// -- the per-block window sums -- goes through canon().  Partial sums that stay on the device (one
+// XYZZ point per task) are stored as they are; every kernel that reads them computes in FpI too.
+__device__ __forceinline__ Xyzz<FpI> canon(const Xyzz<FpI> &p) {
+    return Xyzz<FpI>{FpI{fp_canon(p.x)}, FpI{fp_canon(p.y)}, FpI{fp_canon(p.zz)}, FpI{fp_canon(p.zzz)}};
+}
+__device__ __forceinline__ const Xyzz<Fp2> &canon(const Xyzz<Fp2> &p) { return p; }
+__device__ __forceinline__ const Xyzz<Fp> &canon(const Xyzz<Fp> &p) { return p; }
 
 template <class F>
 __global__ void __launch_bounds__(256)
@@ -441,15 +449,17 @@ template <class T> static __device__ __noinline__ void xyzz_dbl_o(Xyzz<T> *r, co
 // 2..8 tasks: one thread per bucket
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_fold_small(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                  const uint32_t *__restrict__ split_counts) {
+    using T = typename AccumField<F>::T;              // G1: FpI, like the kernel that wrote the partials
+    Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
     for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < n; h += gridDim.x * 256u) {
         const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
-        Xyzz<F> acc = partial[t0];
+        Xyzz<T> acc = partial[t0];
         for (uint32_t t = t0 + 1; t < t1; t++) {
-            Xyzz<F> pt = partial[t];
-            xyzz_add_o<F>(&acc, &acc, &pt);
+            Xyzz<T> pt = partial[t];
+            xyzz_add_o<T>(&acc, &acc, &pt);
         }
         partial[t0] = acc;
     }
@@ -457,26 +467,28 @@ k_msm_fold_small(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ tas
 // more than 8 tasks: one block per bucket -- 256 strided serial chains, shuffle tree, LDS step
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_fold_big(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                const uint32_t *__restrict__ split_counts) {
-    __shared__ Xyzz<F> sm[4];
+    using T = typename AccumField<F>::T;              // G1: FpI, like the kernel that wrote the partials
+    Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
+    __shared__ Xyzz<T> sm[4];
     const uint32_t nh = split_counts[1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
-        Xyzz<F> acc = xyzz_inf<F>();
+        Xyzz<T> acc = xyzz_inf<T>();
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
-            Xyzz<F> pt = partial[t];
-            xyzz_add_o<F>(&acc, &acc, &pt);
+            Xyzz<T> pt = partial[t];
+            xyzz_add_o<T>(&acc, &acc, &pt);
         }
         for (int off = 32; off >= 1; off >>= 1) {
-            Xyzz<F> o = shfl_down(acc, off);
-            if (lane < off) xyzz_add_o<F>(&acc, &acc, &o);
+            Xyzz<T> o = shfl_down(acc, off);
+            if (lane < off) xyzz_add_o<T>(&acc, &acc, &o);
         }
         if (lane == 0) sm[wave] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 1; k < 4; k++) xyzz_add_o<F>(&acc, &acc, &sm[k]);
+            for (int k = 1; k < 4; k++) xyzz_add_o<T>(&acc, &acc, &sm[k]);
             partial[t0] = acc;
         }
         __syncthreads();
@@ -536,13 +548,15 @@ template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &
 // on a few hundred lanes cost 0.19 ms at 2^16, where the 9-bit top window holds 128 records per bucket)
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_fold_small4(Xyzz<F> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+k_msm_fold_small4(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                   const uint32_t *__restrict__ split_counts) {
+    using T = typename AccumField<F>::T;              // G1: FpI, like the kernel that wrote the partials
+    Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
     const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
     for (uint32_t h = blockIdx.x * 64u + (threadIdx.x >> 2); h < n; h += gridDim.x * 64u) {   // uniform in the group
         const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
-        Xyzz<F> acc = partial[t0];
+        Xyzz<T> acc = partial[t0];
         for (uint32_t t = t0 + 1; t < t1; t++) acc = add4(acc, partial[t], r, gb);
         if (r == 0) partial[t0] = acc;
     }
@@ -597,7 +611,7 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (wave == 0 && lane < 4) {
         for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
-        if (lane == 0) winout[blockIdx.x] = C;
+        if (lane == 0) winout[blockIdx.x] = canon(C);
     }
 }
 
@@ -650,7 +664,7 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; k++) xyzz_add_o<T>(&C, &C, &sm[k]);
-        winout[blockIdx.x] = C;
+        winout[blockIdx.x] = canon(C);
     }
 }
 
@@ -899,10 +913,10 @@ k_msm_reduce_batch(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restr
         __syncthreads();
         if (wave == 0 && lane < 4) {
             for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
-            if (lane == 0) winout[unit] = C;
+            if (lane == 0) winout[unit] = canon(C);
         }
     } else if (lane == 0) {
-        winout[unit] = C;
+        winout[unit] = canon(C);
     }
 }
 
