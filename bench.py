@@ -92,6 +92,20 @@ def stats_ms(samples):
             "max": max(samples), "n": len(samples)}
 
 
+class stdout_to_stderr:
+    """Backends print connection chatter ("[Gloo] Rank 0 is connected to ...") to the C-level stdout; the
+    driver expects ONE JSON line there, so rendezvous runs with fd 1 pointed at stderr."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -216,15 +230,14 @@ def main():
     dev_index = local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dist = None
-    cpu_group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-            cpu_group = dist.new_group(backend="gloo")      # host-side waits that must not spin on the GPUs
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     X.init(dev_index)                     # one process per GPU: pin the library to this rank's device
     if args.window:
@@ -395,12 +408,14 @@ def main():
             ok = ok and X.dev_call(FULL[wl], d_s.data_ptr(), sample_n) == cpu_out
         result["cpu_baseline"] = {
             "value": sample_n / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "%s 2^%d records of the same workload, oracle %s (reference control flow: Bos-Coster / sequential Miller loops), one run of %.1f s; host has %d cores"
-                      % ("all" if sample_n == n_local else "first", sample_n.bit_length() - 1, ORACLE[wl], dt, os.cpu_count() or 0),
+            "sample": "%s 2^%d records of the same workload, oracle %s (reference control flow: Bos-Coster / sequential Miller loops), one run of %.1f s; host has %d cores (%d usable by this process)"
+                      % ("all" if sample_n == n_local else "first", sample_n.bit_length() - 1, ORACLE[wl], dt, os.cpu_count() or 0,
+                         len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0),
             "gpu_matches_cpu_on_sample": bool(ok),
         }
         if wl == "g1msm":
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(cores, 64)                 # the windows of the oracle's bucket method are the unit of work: ~20 of them
             t1 = time.perf_counter()
             rc, mt_out = clib.g1_pippenger_mt(sample, cores)
             dt = time.perf_counter() - t1
@@ -451,7 +466,8 @@ def main():
 
     # ---- N > 1: the same total input through the reference ABI of ONE process, cut over the N
     # devices inside the library (thread per device, host combine).  Runs in a fresh child of rank 0
-    # while the other ranks wait on the host (gloo), their GPUs idle.
+    # while the other ranks wait on the host (a key in the rendezvous store: no collective spinning on
+    # their GPUs), their GPUs idle.
     if world > 1 and wl in ("g1msm", "pairing") and not args.no_host_abi:
         if rank == 0:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
@@ -464,12 +480,16 @@ def main():
                 result["in_library_split"] = json.loads(line[-1]) if cp.returncode == 0 and line else {"error": (cp.stderr or cp.stdout)[-400:]}
             except Exception as ex:                          # the headline number must survive this leg
                 result["in_library_split"] = {"error": repr(ex)}
-        dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("eip2537_split_leg_done", "1")
+        else:
+            store.wait(["eip2537_split_leg_done"])
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+        dist.barrier()
         dist.destroy_process_group()
 
 
