@@ -252,7 +252,7 @@ k_msm_slicescan(const uint32_t *__restrict__ hist16, MsmPlan pl, uint32_t nslice
 
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries) {
+              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries, uint32_t passes) {
     __shared__ uint32_t h[kLdsWords];
     // XCD-aware block order (speed only): blocks are dealt round-robin over the 8 XCDs, so block ids
     // with equal id % 8 share an L2.  All slices of a window go to one such group: the window's
@@ -269,13 +269,23 @@ k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices,
     const uint32_t *brow = base + ((size_t)w * nslices + slice) * nbmax;
     const uint32_t *orow = offsets + (size_t)w * pl.B;
     const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-        const uint32_t v = digits[(size_t)w * pl.n + i];
-        if (v) {
-            const uint32_t b = (v >> 1) - 1u, sh = 16u * (b & 1u);
-            const uint32_t rank = (atomicAdd(&h[b >> 1], 1u << sh) >> sh) & 0xffffu;
-            entries[orow[b] + brow[b] + rank] = (i << 1) | (v & 1u);
+    // The window's entries region (4 B x n: 4 MB at 2^20) is as large as the XCD's whole L2, so with the
+    // streamed digit / offset rows passing through the same cache the 4-byte stores left as partial
+    // lines (610 MB written for 67 MB of entries).  The slice is therefore scanned `passes` times, each
+    // pass placing only the entries of one contiguous range of buckets: the 32 blocks of the window (one
+    // XCD) then work on 1 / passes of the region at a time, which stays resident until its lines are full.
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        const uint32_t blo = (uint32_t)((uint64_t)nbw * pass / passes), bhi = (uint32_t)((uint64_t)nbw * (pass + 1) / passes);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+            const uint32_t v = digits[(size_t)w * pl.n + i];
+            if (v) {
+                const uint32_t b = (v >> 1) - 1u, sh = 16u * (b & 1u);
+                if (b < blo || b >= bhi) continue;
+                const uint32_t rank = (atomicAdd(&h[b >> 1], 1u << sh) >> sh) & 0xffffu;
+                entries[orow[b] + brow[b] + rank] = (i << 1) | (v & 1u);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -750,6 +760,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
+    static const uint32_t env_sp = [] { const char *v = getenv("EIP2537_SCATTER_PASSES"); return v ? (uint32_t)atoi(v) : 0u; }();
+    const uint32_t scatter_passes = env_sp ? env_sp : (n >= (1u << 19) ? 4u : n >= (1u << 18) ? 2u : 1u);   // measured: profiles/r02_scatter_passes.txt
     hipStream_t s = e->stream;
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
@@ -790,7 +802,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
@@ -959,6 +971,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
+    const uint32_t scatter_passes = 1u;
     hipStream_t s = e->stream;
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
     auto *err = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->misc.p) + 64);        // [M]
@@ -997,7 +1010,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
