@@ -95,4 +95,10 @@ int msm_g2_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M
 // exponentiation) as 144 Montgomery words to `ml_words`.
 int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words);
 
+// Coalesced batch of M small pairing calls (pairing.hip): d_in holds the calls' pairs back to back, coff[0..M]
+// their pair offsets (host).  Writes rc[j] and per call the 68 per-step line products (Fp12, 144 words each)
+// to L_words[(j * 68 + step) * 144]; the caller applies miller_product_from_steps and the final exponentiation.
+static constexpr int kPairBatchMaxCalls = 64, kPairBatchMaxPairs = 64, kPairSteps = 68;
+int pairing_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M, uint32_t *L_words, int *rc);
+
 }  // namespace eip

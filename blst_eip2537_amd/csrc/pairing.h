@@ -147,6 +147,20 @@ HD Fp12 miller_loop(const Aff<Fp> &P, const Aff<Fp2> &Q) {
     return conj(f);
 }
 
+// The batched form of the loop above (pairing.hip): with L_s the product over all pairs of their line at
+// step s (68 steps: 63 doublings, 5 additions), the product of the pairs' Miller functions is
+// (...((L_0)^2 L_1)^2 ...), squared before every doubling step, conjugated because z < 0.
+HD Fp12 miller_product_from_steps(const Fp12 *L) {
+    Fp12 F = fp12_one();
+    const uint64_t z = K_Z_ABS;
+    int si = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        F = mul(sqr(F), L[si++]);
+        if ((z >> bit) & 1ull) F = mul(F, L[si++]);
+    }
+    return conj(F);
+}
+
 // ------------------------------------------------------------------ final exponentiation
 // Squaring in the cyclotomic subgroup (Granger-Scott): three Fp4 squarings = 9 Fp2 squarings.
 // Valid only after the easy part of the final exponentiation; proven equal to the generic

@@ -108,6 +108,24 @@ __device__ __forceinline__ Xyzz<Fp> g1_mul_zabs4(const Xyzz<Fp> &p, int r, int g
 }
 struct Prod4 { Fp2 r0, r1, r2, r3; };      // the four Fp2 products of one round of a lane group
 
+// Coalesced batches (several small calls' pairs back to back, api.hip): every call has its own
+// first-error word; pair i belongs to the call j with coff[j] <= i < coff[j + 1].  A single call is the
+// map with M = 1 (no table).
+struct CallMap { const uint32_t *coff; int M; };
+__device__ __forceinline__ void report_pair_error(unsigned long long *err, const CallMap &cm, uint32_t i, unsigned long long stage_code) {
+    uint32_t j = 0, local = i;
+    if (cm.M > 1) {
+        int lo = 0, hi = cm.M;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cm.coff[mid] <= i) lo = mid; else hi = mid;
+        }
+        j = (uint32_t)lo;
+        local = i - cm.coff[j];
+    }
+    atomicMin(&err[j], ((unsigned long long)local << 4) | stage_code);
+}
+
 // ---- wire decode, two lanes per pair ------------------------------------------------------------
 // Lane 0 of a pair decodes and validates P (pad / < p / on curve), lane 1 does Q; both store the
 // Montgomery-form point and a "finite and valid" flag.  The walk and membership kernels then start
@@ -117,19 +135,19 @@ struct Prod4 { Fp2 r0, r1, r2, r3; };      // the four Fp2 products of one round
 // reference's order inside a pair (src/eip2537.c:1036-1053); atomicMin keeps the first.
 __global__ void __launch_bounds__(256)
 k_pair_decode(const uint32_t *__restrict__ in, uint32_t k, Aff<Fp> *__restrict__ pmont, Aff<Fp2> *__restrict__ qmont,
-              uint8_t *__restrict__ flagP, uint8_t *__restrict__ flagQ, unsigned long long *err) {
+              uint8_t *__restrict__ flagP, uint8_t *__restrict__ flagQ, unsigned long long *err, CallMap cm) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x, i = t >> 1;
     if (i >= k) return;
     if ((t & 1u) == 0) {
         Aff<Fp> P;
         const int st = decode_point<Fp>(P, in + (size_t)i * kPairWords);
-        if (st != E_SUCCESS) { atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)st); P = Aff<Fp>{fp_zero(), fp_zero()}; }
+        if (st != E_SUCCESS) { report_pair_error(err, cm, i, (unsigned long long)st); P = Aff<Fp>{fp_zero(), fp_zero()}; }
         pmont[i] = P;
         flagP[i] = (st == E_SUCCESS && !is_inf(P)) ? 1 : 0;
     } else {
         Aff<Fp2> Q;
         const int st = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
-        if (st != E_SUCCESS) { atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)st); Q = Aff<Fp2>{fp2_zero(), fp2_zero()}; }
+        if (st != E_SUCCESS) { report_pair_error(err, cm, i, 8ull | (unsigned long long)st); Q = Aff<Fp2>{fp2_zero(), fp2_zero()}; }
         qmont[i] = Q;
         flagQ[i] = (st == E_SUCCESS && !is_inf(Q)) ? 1 : 0;
     }
@@ -138,7 +156,7 @@ k_pair_decode(const uint32_t *__restrict__ in, uint32_t k, Aff<Fp> *__restrict__
 // EXCL: one wave per SIMD (batches whose walk + membership waves fit the chip's 1024 SIMDs)
 template <bool EXCL>
 __global__ void __launch_bounds__(64)
-k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ flagP, uint32_t k, unsigned long long *err) {
+k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ flagP, uint32_t k, unsigned long long *err, CallMap cm) {
     const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
     const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 2);
     if (EXCL) claim_whole_simd();
@@ -149,7 +167,7 @@ k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ f
     const Xyzz<Fp> t = g1_mul_zabs4(g1_mul_zabs4(from_affine(p), r, gb), r, gb);
     const Aff<Fp> phi_neg{g1mul(p.x, Fp{{K_BETA}}), neg(p.y)};
     const bool same = !is_inf(t) && eq(g1mul(phi_neg.x, t.zz), t.x) && eq(g1mul(phi_neg.y, t.zzz), t.y);
-    if (!same && r == 0) atomicMin(err, ((unsigned long long)i << 4) | (unsigned long long)E_NOT_IN_SUBGROUP);
+    if (!same && r == 0) report_pair_error(err, cm, i, (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
 // ---- the addition step and the closing membership test, products dealt over the lanes ---------
@@ -286,7 +304,7 @@ __device__ __forceinline__ void miller_dbl_step_lanes(MillerT &T, PF &&prod, Lin
 template <int LANES>
 __device__ __forceinline__ void pair_walk(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP,
                                           const uint8_t *__restrict__ flagQ, uint32_t k, LineRec *__restrict__ lines,
-                                          unsigned long long *err, Aff<Fp2> *sQ) {
+                                          unsigned long long *err, Aff<Fp2> *sQ, const CallMap &cm) {
     constexpr int kGroups = 64 / LANES;
     const int lane = threadIdx.x & 63, sl = lane & (LANES - 1), gbase = lane & ~(LANES - 1), gi = lane / LANES;
     const uint32_t i = blockIdx.x * (uint32_t)kGroups + (uint32_t)gi;
@@ -329,7 +347,7 @@ __device__ __forceinline__ void pair_walk(const Aff<Fp2> *__restrict__ qmont, co
     }
     const Aff<Fp2> Q = sQ[gi];
     if (!g2_membership_lanes(T, Q, prod) && sl == 0)
-        atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+        report_pair_error(err, cm, i, 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 // ---- 8 lanes per pair, split by Fp2 component ---------------------------------------------------
 // In the replicated form above every lane holds whole Fp2 values and repeats every linear step on both
@@ -406,7 +424,7 @@ __device__ __forceinline__ void miller_add_step_c(TcFp &T, const Fp &Qx, const F
 }
 __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP,
                                             const uint8_t *__restrict__ flagQ, uint32_t k, LineRec *__restrict__ lines,
-                                            unsigned long long *err, Aff<Fp2> *sQ) {
+                                            unsigned long long *err, Aff<Fp2> *sQ, const CallMap &cm) {
     const int lane = threadIdx.x & 63, sl = lane & 7, gbase = lane & ~7, gi = lane >> 3, q = sl & 1;
     const uint32_t i = blockIdx.x * 8u + (uint32_t)gi;
     bool q_live = false, contributes = false;
@@ -453,30 +471,30 @@ __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, 
     same &= __shfl(same, lane ^ 1, 64);                                         // both components
     zzero &= __shfl(zzero, lane ^ 1, 64);
     if ((!same || zzero) && sl == 0)
-        atomicMin(err, ((unsigned long long)i << 4) | 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
+        report_pair_error(err, cm, i, 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
 __global__ void __launch_bounds__(64)
 k_pair_lines4(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
-              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err, CallMap cm) {
     __shared__ Aff<Fp2> sQ[16];
-    pair_walk<4>(qmont, flagP, flagQ, k, lines, err, sQ);
+    pair_walk<4>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
 }
 __global__ void __launch_bounds__(64)
 k_pair_lines8(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
-              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err, CallMap cm) {
     __shared__ Aff<Fp2> sQ[8];
 #if EIP_WALK8_SPLIT
-    pair_walk8c(qmont, flagP, flagQ, k, lines, err, sQ);
+    pair_walk8c(qmont, flagP, flagQ, k, lines, err, sQ, cm);
 #else
-    pair_walk<8>(qmont, flagP, flagQ, k, lines, err, sQ);
+    pair_walk<8>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
 #endif
 }
 __global__ void __launch_bounds__(64)
 k_pair_lines16(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
-               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err) {
+               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err, CallMap cm) {
     __shared__ Aff<Fp2> sQ[4];
-    pair_walk<16>(qmont, flagP, flagQ, k, lines, err, sQ);
+    pair_walk<16>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
 }
 
 // ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
@@ -670,19 +688,99 @@ k_pair_tree2(const Fp2 *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ s
     if (lane < 6) step_out[(size_t)s * 6 + tower_slot(lane)] = acc;
 }
 
+// Coalesced batch: grid (calls, 68 steps), one block per (call, step).  A call of the batch has at most
+// 32 * group_lines pairs, so one block folds all its lines of a step and its output IS that call's L_s
+// ([call][step][6] Fp2, tower layout).
+__global__ void __launch_bounds__(256, 2)
+k_pair_tree_batch(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__ pmont, uint32_t k, const uint32_t *__restrict__ coff,
+                  Fp2 *__restrict__ step_out, uint32_t group_lines) {
+    __shared__ Fp2 sm[4][6];
+    const int j = blockIdx.x, s = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, gbase = lane & ~7;
+    const uint32_t base = coff[j], kj = coff[j + 1] - base;
+    const uint32_t g = threadIdx.x >> 3;                       // 32 groups
+    Fp2 acc = sub == 0 ? fp2_one() : fp2_zero();
+    if (g * group_lines < kj) {
+        const uint32_t i = base + g * group_lines;
+        LineRec l = lines[(size_t)s * k + i];
+        scale_line(l, pmont[i], sub, gbase);
+        acc = sub == 0 ? l.a0 : sub == 2 ? l.a1 : sub == 3 ? l.a4 : fp2_zero();
+    }
+    for (uint32_t t = 1; t < group_lines; t++) {
+        const uint32_t li = g * group_lines + t;
+        if (li < kj) {
+            const uint32_t i = base + li;
+            LineRec l = lines[(size_t)s * k + i];
+            scale_line(l, pmont[i], sub, gbase);
+            acc = grp_mul_line(acc, l, sub, gbase);
+        }
+    }
+    const uint32_t ngroups = (kj + group_lines - 1) / group_lines;
+    const int live_blk = (int)min(32u, ngroups);
+    const int live_wave = max(0, min(8, live_blk - 8 * wave));
+    wave_group_product<2>(acc, lane, sub, gbase, live_wave);
+    Fp2 *out = step_out + ((size_t)j * kSteps + s) * 6;
+    if (live_blk <= 8) {                       // uniform in the block: wave 0 alone holds the product
+        if (wave == 0 && lane < 6) out[tower_slot(lane)] = acc;
+        return;
+    }
+    if (lane < 6) sm[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+        const int gq = lane >> 3, sidx = sub < 6 ? sub : 0;
+        acc = grp_mul_dense<2>(sm[2 * gq][sidx], sm[2 * gq + 1][sidx], sub, gbase);
+        const Fp2 partner = shfl_from(acc, 8 + sub);
+        if (gq == 0 && live_blk > 16) acc = grp_mul_dense<2>(acc, partner, sub, 0);
+        if (lane < 6) out[tower_slot(lane)] = acc;
+    }
+}
+
+// Decode, membership and line walk of K pairs that belong to M calls (M = 1: one call, no table): the
+// part of the device pipeline a single call and a coalesced batch share.  `d_coff` is the device copy of
+// the call offsets (nullptr for M = 1).  Leaves ev_a / ev_b around the walk and the fork joined.
+static int pairing_front(Engine *e, const uint32_t *in, size_t k, const uint32_t *d_coff, int M, unsigned long long *err,
+                         LineRec *lines, Aff<Fp> *pmont, Aff<Fp2> *qmont, uint8_t *flagP, uint8_t *flagQ) {
+    // 16 lanes per pair shorten the serial chain (small batches) but replicate the linear steps more and put
+    // a wave on every SIMD at 2^12 pairs: by size
+    const bool wide = k <= 2048;
+    // 8 lanes per pair while walk + G1 membership waves still find a SIMD each (k/8 + k/16 <= ~1000)
+    static const int env_l8 = [] { const char *v = getenv("EIP2537_LINES8"); return v ? atoi(v) : 1; }();
+    const bool mid = !wide && k <= 5120 && env_l8;
+    const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : mid ? (uint32_t)((k + 7) / 8) : (uint32_t)((k + 15) / 16);
+    {
+        LastPlan lp{};
+        snprintf(lp.kernel, sizeof lp.kernel, "%s", wide ? "k_pair_lines16" : mid ? "k_pair_lines8" : "k_pair_lines4");
+        lp.windows = kSteps; lp.lanes = wide ? 16 : mid ? 8 : 4; lp.units = (uint32_t)k;
+        e->last_plan = lp;
+    }
+    const CallMap cm{d_coff, M};
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemsetAsync(err, 0xFF, (size_t)M * 8, s));
+    HIPCHK(hipEventRecord(e->ev_start, s));
+    hipLaunchKernelGGL(k_pair_decode, dim3((uint32_t)((2 * k + 255) / 256)), dim3(256), 0, s, in, (uint32_t)k, pmont, qmont, flagP, flagQ, err, cm);
+    HIPCHK(hipEventRecord(e->ev_j3, s));
+    // fork: the G1 membership kernel runs beside the line walk
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_j3, 0));
+    const uint32_t check_blocks = (uint32_t)((k + 15) / 16);
+    if (line_blocks + check_blocks <= 1024u)
+        hipLaunchKernelGGL(k_pair_check_g1<true>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err, cm);
+    else
+        hipLaunchKernelGGL(k_pair_check_g1<false>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err, cm);
+    HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
+    HIPCHK(hipEventRecord(e->ev_a, s));
+    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
+    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
+    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
+    HIPCHK(hipEventRecord(e->ev_b, s));
+    return E_SUCCESS;
+}
+
 int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     if (k == 0 || k >= (1ull << 27)) return E_MEMORY_ERROR;
     if ((reinterpret_cast<uintptr_t>(d_in) & 3u) != 0) {
         fprintf(stderr, "[eip2537_hip] device input must be 4-byte aligned\n");
         return E_MEMORY_ERROR;
     }
-    // 16 lanes per pair shorten the serial chain (small batches: 16 pairs 3.1 -> 2.7 ms) but replicate
-    // the linear steps 4x more and put a wave on every SIMD at 2^12 pairs (3.4 vs 2.0 ms): by size
-    const bool wide = k <= 2048;
-    // 8 lanes per pair while walk + G1 membership waves still find a SIMD each (k/8 + k/16 <= ~1000)
-    static const int env_l8 = [] { const char *v = getenv("EIP2537_LINES8"); return v ? atoi(v) : 1; }();
-    const bool mid = !wide && k <= 5120 && env_l8;
-    const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : mid ? (uint32_t)((k + 7) / 8) : (uint32_t)((k + 15) / 16);
     // lines folded serially per 8-lane group: as few as possible while the whole grid (blocks x 68
     // steps) still fits in ONE round of 2 blocks per CU (512 slots); one block more than that and
     // the kernel takes two block-times (measured: 544 blocks 1.8 ms)
@@ -701,32 +799,9 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     auto *flagP = reinterpret_cast<uint8_t *>(qmont + k), *flagQ = flagP + k;
     auto *blk_out = reinterpret_cast<Fp2 *>(e->winout.p);                 // [step][block] tower-layout Fp12
     auto *step_out = blk_out + (size_t)kSteps * tree_blocks * 6;           // [step] Fp12
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
-
-    {
-        LastPlan lp{};
-        snprintf(lp.kernel, sizeof lp.kernel, "%s", wide ? "k_pair_lines16" : mid ? "k_pair_lines8" : "k_pair_lines4");
-        lp.windows = kSteps; lp.lanes = wide ? 16 : mid ? 8 : 4; lp.units = (uint32_t)k;
-        e->last_plan = lp;
-    }
     hipStream_t s = e->stream;
-    HIPCHK(hipMemsetAsync(err, 0xFF, 8, s));
-    HIPCHK(hipEventRecord(e->ev_start, s));
-    hipLaunchKernelGGL(k_pair_decode, dim3((uint32_t)((2 * k + 255) / 256)), dim3(256), 0, s, in, (uint32_t)k, pmont, qmont, flagP, flagQ, err);
-    HIPCHK(hipEventRecord(e->ev_j3, s));
-    // fork: the G1 membership kernel runs beside the line walk
-    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_j3, 0));
-    const uint32_t check_blocks = (uint32_t)((k + 15) / 16);
-    if (line_blocks + check_blocks <= 1024u)
-        hipLaunchKernelGGL(k_pair_check_g1<true>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err);
-    else
-        hipLaunchKernelGGL(k_pair_check_g1<false>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err);
-    HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
-    HIPCHK(hipEventRecord(e->ev_a, s));
-    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err);
-    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err);
-    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err);
-    HIPCHK(hipEventRecord(e->ev_b, s));
+    int st = pairing_front(e, reinterpret_cast<const uint32_t *>(d_in), k, nullptr, 1, err, lines, pmont, qmont, flagP, flagQ);
+    if (st) return st;
     // one block per step (k <= 32 group_lines): its output IS L_s, same [step][6] layout as step_out
     hipLaunchKernelGGL(k_pair_tree, dim3(tree_blocks, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k,
                        tree_blocks == 1 ? step_out : blk_out, group_lines);
@@ -744,19 +819,52 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
     if (herr != ~0ull) return (int)(herr & 7ull);
-
-    // F = (...((L_0)^2 L_1)^2 ...): square before every doubling step, conjugate because z < 0
     // (folding the k sparse lines of a step on the host instead of launching the tree was tried for
     // k <= 4: it won while the tree cost 0.42 ms, and lost -- 2.8 vs 2.4 ms at k = 4 -- once it did not)
-    Fp12 F = fp12_one();
-    const uint64_t z = K_Z_ABS;
-    int si = 0;
-    for (int bit = 62; bit >= 0; bit--) {
-        F = mul(sqr(F), L[si++]);
-        if ((z >> bit) & 1ull) F = mul(F, L[si++]);
-    }
-    F = conj(F);
+    const Fp12 F = miller_product_from_steps(L.data());
     memcpy(ml_words, &F, sizeof F);
+    return E_SUCCESS;
+}
+
+// Coalesced batch of M small pairing calls (each at most kPairBatchMaxPairs pairs; api.hip): one decode /
+// membership / walk over the concatenated pairs with a first-error word per call, one product-tree block
+// per (call, step).  Writes rc[j] and, for the good calls, their 68 per-step products to L (the caller
+// finishes with miller_product_from_steps and the final exponentiation on its own thread).
+int pairing_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int M, uint32_t *L_words, int *rc) {
+    const size_t k = coff[M];
+    if (M < 1 || M > kPairBatchMaxCalls || k == 0 || k > 8192) return E_MEMORY_ERROR;
+    uint32_t kmax = 0;
+    for (int j = 0; j < M; j++) kmax = std::max(kmax, coff[j + 1] - coff[j]);
+    if (kmax == 0 || kmax > (uint32_t)kPairBatchMaxPairs) return E_MEMORY_ERROR;
+    const uint32_t group_lines = (kmax + 31u) / 32u;
+    HIPCHK(e->misc.reserve(64 + (size_t)M * 8 + (size_t)(M + 1) * 4));
+    HIPCHK(e->pts.reserve(k * sizeof(Aff<Fp>)));
+    HIPCHK(e->digits.reserve(k * sizeof(Aff<Fp2>) + 2 * k + 64));
+    HIPCHK(e->partial.reserve((size_t)kSteps * k * sizeof(LineRec)));
+    HIPCHK(e->winout.reserve((size_t)M * kSteps * sizeof(Fp12)));
+    auto *err = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->misc.p) + 64);              // [M]
+    auto *d_coff = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 64 + (size_t)M * 8);     // [M + 1]
+    auto *lines = reinterpret_cast<LineRec *>(e->partial.p);
+    auto *pmont = reinterpret_cast<Aff<Fp> *>(e->pts.p);
+    auto *qmont = reinterpret_cast<Aff<Fp2> *>(e->digits.p);
+    auto *flagP = reinterpret_cast<uint8_t *>(qmont + k), *flagQ = flagP + k;
+    auto *step_out = reinterpret_cast<Fp2 *>(e->winout.p);                // [call][step] Fp12
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(d_coff, coff, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
+    int st = pairing_front(e, reinterpret_cast<const uint32_t *>(d_in), k, d_coff, M, err, lines, pmont, qmont, flagP, flagQ);
+    if (st) return st;
+    hipLaunchKernelGGL(k_pair_tree_batch, dim3((uint32_t)M, kSteps), dim3(256), 0, s, lines, pmont, (uint32_t)k, d_coff, step_out, group_lines);
+    HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
+    HIPCHK(hipEventRecord(e->ev_stop, s));
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> herr((size_t)M);
+    HIPCHK(hipMemcpyAsync(herr.data(), err, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(L_words, step_out, (size_t)M * kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
+    for (int j = 0; j < M; j++) rc[j] = herr[(size_t)j] != ~0ull ? (int)(herr[(size_t)j] & 7ull) : E_SUCCESS;
     return E_SUCCESS;
 }
 

@@ -79,9 +79,9 @@ int eip2537_hip_gen_g2_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32],
 int eip2537_hip_gen_pairing_input(uint8_t *out, size_t k, const uint8_t a0[32], const uint8_t a1[32],
                                   const uint8_t b0[32], const uint8_t b1[32], uint64_t start);
 
-/* Concurrent small multiexp calls (2..512 records, host input) are coalesced: callers that arrive while
- * the engine is busy are served together by ONE device pipeline over their concatenated records, each
- * with its own result and error code ($EIP2537_HIP_COALESCE=0 disables).  Counters since load: device
+/* Concurrent small calls (multiexp of 3..512 records, pairing checks of 5..64 pairs, host input) are
+ * coalesced: callers that arrive while the engine is busy are served together by ONE device pipeline over
+ * their concatenated records, each with its own result and error code ($EIP2537_HIP_COALESCE=0 disables).  Counters since load: device
  * pipelines run for such calls, calls served, and the largest number of calls in one pipeline. */
 void eip2537_hip_coalesce_stats(uint64_t *pipelines, uint64_t *calls, uint64_t *largest_batch);
 

@@ -77,3 +77,42 @@ def test_concurrent_small_g2_and_mixed_calls(X, clib):
     pr = clib.gen_pairing_input(4, 5, 7, 11, 13)
     jobs.append((X.pairing, pr, clib.call("bls12_pairing", pr)))
     assert _hammer(jobs) == []
+
+
+def _pairing_case(clib, k, seed, delta):
+    """k pairs of generator multiples whose product is one iff delta == 0."""
+    a0, a1, b0, b1 = 5 + seed, 7 + 2 * seed, 11 + 3 * seed, 13 + seed
+    buf = bytearray(clib.gen_pairing_input(k, a0, a1, b0, b1))
+    s = sum((a0 + i * a1) * (b0 + i * b1) for i in range(k - 1)) % m.R
+    buf[(k - 1) * 384:] = m.encode_g1(m.g1_mul(m.G1, (delta - s) % m.R)) + m.encode_g2(m.G2)
+    return bytes(buf)
+
+
+def test_concurrent_small_pairing_calls_are_coalesced_and_exact(X, clib):
+    rng = m.SplitMix64(21)
+    jobs = []
+    for i, k in enumerate([5, 6, 8, 9, 16, 17, 31, 32, 33, 48, 64, 5, 7, 12]):
+        good = _pairing_case(clib, k, i, 0)
+        jobs.append((X.pairing, good, (0, bytes(31) + b"\x01")))
+        if i % 3 == 0:
+            jobs.append((X.pairing, _pairing_case(clib, k, i, 1), (0, bytes(32))))
+    inf = bytearray(_pairing_case(clib, 6, 3, 0))                 # pairs with a point at infinity contribute one
+    jobs.append((X.pairing, bytes(inf[:5 * 384]) + m.encode_g1(None) + m.encode_g2(m.G2), clib.call("bls12_pairing", bytes(inf[:5 * 384]) + m.encode_g1(None) + m.encode_g2(m.G2))))
+    # failing calls keep their own code: G1 subgroup at pair 4, G2 off curve at pair 2 (wins), pad byte in pair 0
+    bad = bytearray(_pairing_case(clib, 8, 5, 0))
+    bad[4 * 384:4 * 384 + 128] = m.encode_g1(m.random_g1(rng, False))
+    jobs.append((X.pairing, bytes(bad), (2, None)))
+    bad[2 * 384 + 128:2 * 384 + 384] = m.encode_fp(1) * 4
+    jobs.append((X.pairing, bytes(bad), (1, None)))
+    bad2 = bytearray(_pairing_case(clib, 20, 6, 0))
+    bad2[3] = 9
+    jobs.append((X.pairing, bytes(bad2), (3, None)))
+    bad3 = bytearray(_pairing_case(clib, 10, 7, 0))
+    bad3[9 * 384 + 128:9 * 384 + 384] = m.encode_g2(m.random_g2(rng, False))     # G2 subgroup, last pair
+    jobs.append((X.pairing, bytes(bad3), (2, None)))
+    for fn, inp, want in jobs[:6]:
+        assert clib.call("bls12_pairing", inp) == want            # the oracle agrees with the constructed expectation
+    before = X.coalesce_stats()
+    assert _hammer(jobs, rounds=2) == []
+    pipelines, calls, _ = (b - a for a, b in zip(before, X.coalesce_stats()))
+    assert calls == 2 * len(jobs) and pipelines < calls

@@ -29,6 +29,7 @@ def main():
         "g1msm_4096": ("g1_multiexp", ex.gen_msm_input("g1", 4096, 3, 5, 7)),
         "g2msm_128": ("g2_multiexp", ex.gen_msm_input("g2", 128, 3, 5, 7)),
         "pairing_2": ("pairing", ex.gen_pairing_input(2, 3, 5, 7, 11)),
+        "pairing_8": ("pairing", ex.gen_pairing_input(8, 3, 5, 7, 11)),
         "pairing_16": ("pairing", ex.gen_pairing_input(16, 3, 5, 7, 11)),
     }
     slots = os.environ.get("EIP2537_HIP_SLOTS", "8 (default)")
