@@ -10,12 +10,12 @@
 //        F = prod_i f_i,   f_i = (...((l_{i,0})^2 l_{i,1})^2 ...)        =>
 //        F = (...((L_0)^2 L_1)^2 ...),   L_s = prod_i l_{i,s}
 // because squaring distributes over the product.  So:
-//   k_pair_lines4/16 [pair, 4 or 16 lanes each]  walk T = Q, 2Q, ... on the twist (Fp2 only),
-//                           the independent products of a step dealt over the lanes (one Fp2
-//                           product per lane, or one Fp product per lane for batches <= 2048); store the
-//                           68 sparse lines (a0, a1 xP, a4 yP); the walk ends at T = [|z|]Q,
-//                           which IS the G2 membership test psi(Q) == -[|z|]Q
-//   k_pair_check_g1 [pair = 4 lanes]  decode + on-curve + G1 membership phi(P) == -[z^2]P  (second stream)
+//   k_pair_decode  [pair = 2 lanes]  wire decode + validation of P and Q, Montgomery form, flags
+//   k_pair_lines8  [pair = 8 lanes]  walk T = Q, 2Q, ... on the twist, the independent products of a
+//                           step dealt over the lane pairs, each lane holding one Fp2 component; stores
+//                           the 68 sparse lines (a0, a1, a4 -- scaled by xP, yP later); the walk ends at
+//                           T = [|z|]Q, which IS the G2 membership test psi(Q) == -[|z|]Q
+//   k_pair_check_g1 [pair = 4 lanes]  G1 membership phi(P) == -[z^2]P  (second stream, beside the walk)
 //   k_pair_tree    [a run of lines of one step per 8-lane group]  each Fp12 is spread over a lane
 //                           group (one Fp2 coefficient per lane); sparse line products, then a
 //                           per-wave product tree over shuffles and an LDS step across waves
@@ -106,8 +106,6 @@ __device__ __forceinline__ Xyzz<Fp> g1_mul_zabs4(const Xyzz<Fp> &p, int r, int g
     }
     return acc;
 }
-struct Prod4 { Fp2 r0, r1, r2, r3; };      // the four Fp2 products of one round of a lane group
-
 // Coalesced batches (several small calls' pairs back to back, api.hip): every call has its own
 // first-error word; pair i belongs to the call j with coff[j] <= i < coff[j + 1].  A single call is the
 // map with M = 1 (no table).
@@ -170,197 +168,23 @@ k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ f
     if (!same && r == 0) report_pair_error(err, cm, i, (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
-// ---- the addition step and the closing membership test, products dealt over the lanes ---------
-// `prod(a0..a3, b0..b3)` returns the four Fp2 products a_j b_j computed by the lane group (unused slots
-// repeat slot 0).  Same results as miller_add_step (pairing.h); six rounds instead of ~14 replicated
-// Fp2 products per lane.
-template <class PF>
-__device__ __forceinline__ Line miller_add_step_lanes(MillerT &T, const Aff<Fp2> &Q, PF &&prod) {
-    Prod4 pr = prod(T.z, T.z, T.z, T.z, T.z, T.z, T.z, T.z);
-    const Fp2 ZZ = pr.r0;
-    pr = prod(Q.x, ZZ, Q.x, Q.x, ZZ, T.z, ZZ, ZZ);
-    const Fp2 U2 = pr.r0, ZZZ = pr.r1;
-    pr = prod(Q.y, Q.y, Q.y, Q.y, ZZZ, ZZZ, ZZZ, ZZZ);
-    const Fp2 S2 = pr.r0;
-    const Fp2 H = sub(U2, T.x), th = sub(S2, T.y);
-    pr = prod(H, T.z, th, th, H, H, th, Q.x);
-    const Fp2 HH = pr.r0, Z3 = pr.r1, TH2 = pr.r2, thQx = pr.r3;
-    pr = prod(HH, T.x, Z3, HH, H, HH, Q.y, H);
-    const Fp2 HHH = pr.r0, V = pr.r1, Z3Qy = pr.r2;
-    const Fp2 X3 = sub(sub(TH2, HHH), dbl(V));
-    const Fp2 VX = sub(V, X3);
-    pr = prod(th, T.y, th, th, VX, HHH, VX, VX);
-    Line l;
-    l.a0 = sub(thQx, Z3Qy);
-    l.a1 = neg(th);
-    l.a4 = Z3;
-    T.x = X3;
-    T.y = sub(pr.r0, pr.r1);
-    T.z = Z3;
-    return l;
-}
-// T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T:
-//   psi(Q).x Z^2 == X   and   -psi(Q).y Z^3 == Y     (blst_p2_affine_in_g2, reference :1051)
-template <class PF>
-__device__ __forceinline__ bool g2_membership_lanes(const MillerT &T, const Aff<Fp2> &Q, PF &&prod) {
-    const Fp2 cx = conj(Q.x), cy = conj(Q.y);
-    const Fp2 kx{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}}, ky{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}};
-    Prod4 pr = prod(cx, cy, T.z, cx, kx, ky, T.z, kx);
-    const Fp2 px = pr.r0, py = neg(pr.r1), zz = pr.r2;
-    pr = prod(px, zz, px, px, zz, T.z, zz, zz);
-    const Fp2 lhs_x = pr.r0, zzz = pr.r1;
-    pr = prod(py, py, py, py, zzz, zzz, zzz, zzz);
-    return !is_zero(T.z) && eq(lhs_x, T.x) && eq(pr.r0, T.y);
-}
-
-// ---- line walk, 4 / 8 / 16 lanes per pair ------------------------------------------------------
-// A lone wave issues about one VALU instruction every 5-6 cycles, so one pair per lane made the
-// 63-step walk a 2400-product serial chain on 64 waves.  Here a pair owns a lane group: every lane
-// keeps the whole running point T, the independent Fp2 products of a step are dealt over the lanes
-// in rounds of four --
+// ---- line walk: 8 lanes per pair, split by Fp2 component ---------------------------------------
+// A lone wave issues about one VALU instruction every 5-6 cycles, so one pair per lane made the 63-step
+// walk a 2400-product serial chain on 64 waves.  A pair therefore owns a group of 8 lanes = 4 lane pairs;
+// the independent Fp2 products of a step are dealt over the lane pairs in rounds of four --
 //   doubling   [X^2  Y^2  Z^2  YZ]   [B^2  (X+B)^2  E^2  EX]   [E ZZ  Z3 ZZ  E(D-X3)]
-//   addition   six rounds (miller_add_step_lanes above)
-// -- and exchanged with wavefront shuffles; the cheap linear steps are replicated on all lanes.
-//   4 lanes:  lane r computes product r whole (Karatsuba, 3 Fp products per round)
-//   8 lanes:  lane pair p, lane q of it computes component q of product p by the schoolbook rule
-//             (c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0: two Fp products per round, no exchange inside
-//             the pair); at 2^12 pairs that is 512 waves, which leaves SIMDs for the G1 membership
-//             kernel running beside it (the 16-lane form fills every SIMD there and the two serialise)
-//   16 lanes: lane 3p+q computes Karatsuba part q of product p (one Fp product per round); the
-//             triple combines them.  Lanes 12..15 shadow product 3.
-template <int LANES> struct WalkLanes;
-template <> struct WalkLanes<4> {
-    int r, gbase;
-    __device__ __forceinline__ WalkLanes(int sl, int gb) : r(sl), gbase(gb) {}
-    __device__ __forceinline__ Prod4 operator()(const Fp2 &a0, const Fp2 &a1, const Fp2 &a2, const Fp2 &a3,
-                                                const Fp2 &b0, const Fp2 &b1, const Fp2 &b2, const Fp2 &b3) const {
-        const Fp2 pr = fp2_mul_body(sel4(r, a0, a1, a2, a3), sel4(r, b0, b1, b2, b3));
-        return Prod4{shfl_from(pr, gbase), shfl_from(pr, gbase + 1), shfl_from(pr, gbase + 2), shfl_from(pr, gbase + 3)};
-    }
-};
-template <> struct WalkLanes<8> {
-    int p, q, gbase;
-    __device__ __forceinline__ WalkLanes(int sl, int gb) : p(sl >> 1), q(sl & 1), gbase(gb) {}
-    __device__ __forceinline__ Prod4 operator()(const Fp2 &a0, const Fp2 &a1, const Fp2 &a2, const Fp2 &a3,
-                                                const Fp2 &b0, const Fp2 &b1, const Fp2 &b2, const Fp2 &b3) const {
-        const Fp2 u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);
-        const Fp y1 = q ? v.c1 : v.c0, y2 = q ? v.c0 : v.c1;
-        const Fp m1 = fp_mul_cols28(u.c0, y1), m2 = fp_mul_cols28(u.c1, y2);
-        const Fp c = q ? add(m1, m2) : sub(m1, m2);
-        Prod4 o;
-        o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
-        o.r1 = Fp2{shfl_from(c, gbase + 2), shfl_from(c, gbase + 3)};
-        o.r2 = Fp2{shfl_from(c, gbase + 4), shfl_from(c, gbase + 5)};
-        o.r3 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
-        return o;
-    }
-};
-template <> struct WalkLanes<16> {
-    int p, q, tb, gbase;
-    __device__ __forceinline__ WalkLanes(int sl, int gb) : p(sl / 3 < 3 ? sl / 3 : 3), q(sl - 3 * (sl / 3)), tb(gb + 3 * (sl / 3 < 3 ? sl / 3 : 3)), gbase(gb) {}
-    __device__ __forceinline__ Prod4 operator()(const Fp2 &a0, const Fp2 &a1, const Fp2 &a2, const Fp2 &a3,
-                                                const Fp2 &b0, const Fp2 &b1, const Fp2 &b2, const Fp2 &b3) const {
-        const Fp2 u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);
-        // this lane's Karatsuba part of its product
-        const Fp x = q == 0 ? u.c0 : (q == 1 ? u.c1 : add(u.c0, u.c1));
-        const Fp y = q == 0 ? v.c0 : (q == 1 ? v.c1 : add(v.c0, v.c1));
-        const Fp t = fp_mul_cols28(x, y);
-        const Fp t0 = shfl_from(t, tb), t1 = shfl_from(t, tb + 1), t2 = shfl_from(t, tb + 2);
-        const Fp c = q == 0 ? sub(t0, t1) : sub(sub(t2, t0), t1);       // lane q=0: c0, lane q=1: c1
-        Prod4 o;
-        o.r0 = Fp2{shfl_from(c, gbase + 0), shfl_from(c, gbase + 1)};
-        o.r1 = Fp2{shfl_from(c, gbase + 3), shfl_from(c, gbase + 4)};
-        o.r2 = Fp2{shfl_from(c, gbase + 6), shfl_from(c, gbase + 7)};
-        o.r3 = Fp2{shfl_from(c, gbase + 9), shfl_from(c, gbase + 10)};
-        return o;
-    }
-};
-// Lanes 0..2 of the pair's group store a0, a1, a4 UNSCALED: multiplying (a1, a4) by (xP, yP) is left
-// to the product tree (throughput-rich), which takes one Fp product and ~800 instructions per step
-// off the walk's serial chain.  A pair that contributes the identity stores the line 1.
-__device__ __forceinline__ void store_line_part(LineRec *dst, int part, const Fp2 &v, bool contributes, int sl) {
-    if (sl == part) (&dst->a0)[part] = contributes ? v : (part == 0 ? fp2_one() : fp2_zero());
-}
-// same result as miller_dbl_step (pairing.h); the line coefficients are stored as soon as they exist
-// (a0 after the second round) so that their operands do not stay live through the third
-template <class PF>
-__device__ __forceinline__ void miller_dbl_step_lanes(MillerT &T, PF &&prod, LineRec *dst, bool contributes, int sl) {
-    Prod4 pr = prod(T.x, T.y, T.z, T.y, T.x, T.y, T.z, T.z);
-    const Fp2 A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
-    const Fp2 E = add(dbl(A), A), XB = add(T.x, B);
-    pr = prod(B, XB, E, E, B, XB, E, T.x);
-    const Fp2 C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
-    store_line_part(dst, 0, sub(EX, dbl(B)), contributes, sl);                   // 3X^3 - 2Y^2
-    const Fp2 D = dbl(sub(sub(t, A), C));
-    const Fp2 X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
-    const Fp2 C8 = dbl(dbl(dbl(C)));
-    pr = prod(E, Z3, E, E, ZZ, ZZ, sub(D, X3), ZZ);
-    store_line_part(dst, 1, neg(pr.r0), contributes, sl);                        // -3X^2 Z^2
-    store_line_part(dst, 2, pr.r1, contributes, sl);                             // 2YZ^3
-    T.x = X3;
-    T.y = sub(pr.r2, C8);
-    T.z = Z3;
-}
-template <int LANES>
-__device__ __forceinline__ void pair_walk(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP,
-                                          const uint8_t *__restrict__ flagQ, uint32_t k, LineRec *__restrict__ lines,
-                                          unsigned long long *err, Aff<Fp2> *sQ, const CallMap &cm) {
-    constexpr int kGroups = 64 / LANES;
-    const int lane = threadIdx.x & 63, sl = lane & (LANES - 1), gbase = lane & ~(LANES - 1), gi = lane / LANES;
-    const uint32_t i = blockIdx.x * (uint32_t)kGroups + (uint32_t)gi;
-    // Q is only needed by the 5 addition steps and the closing membership test: it waits in LDS
-    // (192 B per pair) instead of occupying 48 VGPRs through the walk
-    bool q_live = false, contributes = false;
-    MillerT T;
-    if (LANES >= 8) claim_whole_simd();       // the forms used while the batch fits one wave per SIMD
-    if (i < k) {                              // uniform within a lane group
-        q_live = flagQ[i] != 0;
-        contributes = q_live && flagP[i] != 0;                   // else the pair contributes 1
-        const Aff<Fp2> Q = qmont[i];
-        if (sl == 0) sQ[gi] = Q;
-        T = MillerT{Q.x, Q.y, fp2_one()};
-    }
-    __syncthreads();
-    if (i >= k) return;
-    if (!q_live) {                            // Q at infinity (or undecodable: reported by the decode)
-        if (sl < 3) {
-            const Fp2 v = sl == 0 ? fp2_one() : fp2_zero();
-            for (int s = 0; s < kSteps; s++) (&lines[(size_t)s * k + i].a0)[sl] = v;
-        }
-        return;
-    }
-    const WalkLanes<LANES> prod(sl, gbase);
-    const uint64_t z = K_Z_ABS;
-    int s = 0;
-    for (int bit = 62; bit >= 0; bit--) {
-        miller_dbl_step_lanes(T, prod, &lines[(size_t)s * k + i], contributes, sl);
-        s++;
-        if ((z >> bit) & 1ull) {              // 5 of 63 steps
-            const Aff<Fp2> Q = sQ[gi];
-            const Line l = miller_add_step_lanes(T, Q, prod);
-            LineRec *dst = &lines[(size_t)s * k + i];
-            store_line_part(dst, 0, l.a0, contributes, sl);
-            store_line_part(dst, 1, l.a1, contributes, sl);
-            store_line_part(dst, 2, l.a4, contributes, sl);
-            s++;
-        }
-    }
-    const Aff<Fp2> Q = sQ[gi];
-    if (!g2_membership_lanes(T, Q, prod) && sl == 0)
-        report_pair_error(err, cm, i, 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
-}
-// ---- 8 lanes per pair, split by Fp2 component ---------------------------------------------------
-// In the replicated form above every lane holds whole Fp2 values and repeats every linear step on both
-// components: a doubling step was ~8 200 instructions of which 2 350 multiply-adds, ~1 800 carry-chain
-// additions / subtractions plus 830 hazard nops, and the running values did not fit the registers
-// (1 GB of scratch stores per launch at 2^12 pairs).  Here lane (p, q) of the pair's group holds only
-// COMPONENT q of every Fp2 value (replicated over the four lane pairs p): the linear steps of both steps
-// are component-wise, so they run on Fp -- half the instructions, half the registers -- and only a
-// product needs the partner lane's component of its two operands (one exchange with lane ^ 1).
-// Lane pair p computes product p of a round by the schoolbook rule, as before.
-#ifndef EIP_WALK8_SPLIT
-#define EIP_WALK8_SPLIT 1
-#endif
+//   addition   six rounds,   closing G2 membership test psi(Q) == -[|z|]Q   three rounds
+// -- and exchanged with wavefront shuffles.  Lane (p, q) holds only COMPONENT q of every Fp2 value
+// (replicated over the four lane pairs p): the linear steps are component-wise, so they run on Fp, and
+// only a product needs the partner lane's component of its two operands (one exchange with lane ^ 1);
+// lane pair p computes product p of a round by the schoolbook rule (c0 = a0 b0 - a1 b1,
+// c1 = a0 b1 + a1 b0: two Fp products per lane).  Round 1 had every lane hold whole Fp2 values and
+// repeat every linear step on both components, in 4-, 8- and 16-lane forms picked by batch size: a
+// doubling step was ~8 200 instructions (2 350 multiply-adds, ~1 800 carry-chain additions /
+// subtractions plus 830 hazard nops, operand selects) with 1 GB of scratch stores per launch at 2^12
+// pairs; this form is ~5 500 without spills to memory, and faster than each of the three at every size
+// (2^12 pairs: walk 1.43 -> 1.04 ms; 2 pairs: check 1.92 -> 1.77 ms; 2^15 pairs: 12.1 -> 10.5 ms), so it
+// is the only one left.
 struct TcFp { Fp x, y, z; };                      // this lane's component of the running point
 struct Prod4c { Fp r0, r1, r2, r3; };             // this lane's component of the four products of a round
 struct Walk8c {
@@ -422,6 +246,7 @@ __device__ __forceinline__ void miller_add_step_c(TcFp &T, const Fp &Qx, const F
     T.y = sub(pr.r0, pr.r1);
     T.z = Z3;
 }
+template <bool EXCL>
 __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP,
                                             const uint8_t *__restrict__ flagQ, uint32_t k, LineRec *__restrict__ lines,
                                             unsigned long long *err, Aff<Fp2> *sQ, const CallMap &cm) {
@@ -429,7 +254,7 @@ __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, 
     const uint32_t i = blockIdx.x * 8u + (uint32_t)gi;
     bool q_live = false, contributes = false;
     TcFp T;
-    claim_whole_simd();
+    if (EXCL) claim_whole_simd();              // batches whose walk + membership waves fit one per SIMD
     if (i < k) {                              // uniform within a lane group
         q_live = flagQ[i] != 0;
         contributes = q_live && flagP[i] != 0;                   // else the pair contributes 1
@@ -474,29 +299,13 @@ __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, 
         report_pair_error(err, cm, i, 8ull | (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
-__global__ void __launch_bounds__(64)
-k_pair_lines4(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
-              uint32_t k, LineRec *__restrict__ lines, unsigned long long *err, CallMap cm) {
-    __shared__ Aff<Fp2> sQ[16];
-    pair_walk<4>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
-}
+template <bool EXCL>
 __global__ void __launch_bounds__(64)
 k_pair_lines8(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err, CallMap cm) {
     __shared__ Aff<Fp2> sQ[8];
-#if EIP_WALK8_SPLIT
-    pair_walk8c(qmont, flagP, flagQ, k, lines, err, sQ, cm);
-#else
-    pair_walk<8>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
-#endif
+    pair_walk8c<EXCL>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
 }
-__global__ void __launch_bounds__(64)
-k_pair_lines16(const Aff<Fp2> *__restrict__ qmont, const uint8_t *__restrict__ flagP, const uint8_t *__restrict__ flagQ,
-               uint32_t k, LineRec *__restrict__ lines, unsigned long long *err, CallMap cm) {
-    __shared__ Aff<Fp2> sQ[4];
-    pair_walk<16>(qmont, flagP, flagQ, k, lines, err, sQ, cm);
-}
-
 // ---- Fp12 spread over a group of 8 lanes ----------------------------------------------------
 // In the product trees an Fp12 element g = sum_k g_k w^k (g_k in Fp2, w^6 = xi) lives in one
 // 8-lane group: lane `sub` (0..5) holds g_sub, lanes 6 and 7 idle.  A lane then needs ~24
@@ -740,17 +549,12 @@ k_pair_tree_batch(const LineRec *__restrict__ lines, const Aff<Fp> *__restrict__
 // the call offsets (nullptr for M = 1).  Leaves ev_a / ev_b around the walk and the fork joined.
 static int pairing_front(Engine *e, const uint32_t *in, size_t k, const uint32_t *d_coff, int M, unsigned long long *err,
                          LineRec *lines, Aff<Fp> *pmont, Aff<Fp2> *qmont, uint8_t *flagP, uint8_t *flagQ) {
-    // 16 lanes per pair shorten the serial chain (small batches) but replicate the linear steps more and put
-    // a wave on every SIMD at 2^12 pairs: by size
-    const bool wide = k <= 2048;
-    // 8 lanes per pair while walk + G1 membership waves still find a SIMD each (k/8 + k/16 <= ~1000)
-    static const int env_l8 = [] { const char *v = getenv("EIP2537_LINES8"); return v ? atoi(v) : 1; }();
-    const bool mid = !wide && k <= 5120 && env_l8;
-    const uint32_t line_blocks = wide ? (uint32_t)((k + 3) / 4) : mid ? (uint32_t)((k + 7) / 8) : (uint32_t)((k + 15) / 16);
+    const uint32_t line_blocks = (uint32_t)((k + 7) / 8), check_blocks = (uint32_t)((k + 15) / 16);
+    const bool excl = line_blocks + check_blocks <= 1024u;       // one wave per SIMD while everything fits the chip
     {
         LastPlan lp{};
-        snprintf(lp.kernel, sizeof lp.kernel, "%s", wide ? "k_pair_lines16" : mid ? "k_pair_lines8" : "k_pair_lines4");
-        lp.windows = kSteps; lp.lanes = wide ? 16 : mid ? 8 : 4; lp.units = (uint32_t)k;
+        snprintf(lp.kernel, sizeof lp.kernel, "%s", excl ? "k_pair_lines8<true>" : "k_pair_lines8<false>");
+        lp.windows = kSteps; lp.lanes = 8; lp.units = (uint32_t)k;
         e->last_plan = lp;
     }
     const CallMap cm{d_coff, M};
@@ -761,16 +565,14 @@ static int pairing_front(Engine *e, const uint32_t *in, size_t k, const uint32_t
     HIPCHK(hipEventRecord(e->ev_j3, s));
     // fork: the G1 membership kernel runs beside the line walk
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_j3, 0));
-    const uint32_t check_blocks = (uint32_t)((k + 15) / 16);
-    if (line_blocks + check_blocks <= 1024u)
+    if (excl)
         hipLaunchKernelGGL(k_pair_check_g1<true>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err, cm);
     else
         hipLaunchKernelGGL(k_pair_check_g1<false>, dim3(check_blocks), dim3(64), 0, e->stream2, pmont, flagP, (uint32_t)k, err, cm);
     HIPCHK(hipEventRecord(e->ev_j2, e->stream2));
     HIPCHK(hipEventRecord(e->ev_a, s));
-    if (wide) hipLaunchKernelGGL(k_pair_lines16, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
-    else if (mid) hipLaunchKernelGGL(k_pair_lines8, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
-    else hipLaunchKernelGGL(k_pair_lines4, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
+    if (excl) hipLaunchKernelGGL(k_pair_lines8<true>, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
+    else hipLaunchKernelGGL(k_pair_lines8<false>, dim3(line_blocks), dim3(64), 0, s, qmont, flagP, flagQ, (uint32_t)k, lines, err, cm);
     HIPCHK(hipEventRecord(e->ev_b, s));
     return E_SUCCESS;
 }
