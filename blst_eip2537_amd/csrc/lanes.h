@@ -63,4 +63,77 @@ __device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
     return o;
 }
 
+// ---- Fp2 values split by component over lane pairs ---------------------------------------------------
+// The lane-group kernels over Fp2 (pairing line walk, G2 bucket reduce) give one logical operation a group
+// of 8 lanes = 4 lane pairs.  Lane (p, q) holds only COMPONENT q of every Fp2 value of the group
+// (replicated over the four pairs p): linear steps are component-wise, so they run on Fp -- half the
+// instructions and registers of lanes that hold whole Fp2 values -- and only a product needs the partner
+// lane's component of its two operands (one exchange with lane ^ 1).  A round multiplies four pairs of
+// operands: lane pair p computes product p by the schoolbook rule (c0 = a0 b0 - a1 b1,
+// c1 = a0 b1 + a1 b0: two Fp products per lane), and every lane gets its component of all four results.
+struct Prod4c { Fp r0, r1, r2, r3; };             // this lane's component of the four products of a round
+struct PairProd8 {
+    int p, q, lane, gbase;
+    __device__ __forceinline__ PairProd8(int lane_, int sl, int gb) : p(sl >> 1), q(sl & 1), lane(lane_), gbase(gb) {}
+    __device__ __forceinline__ Prod4c operator()(const Fp &a0, const Fp &a1, const Fp &a2, const Fp &a3,
+                                                 const Fp &b0, const Fp &b1, const Fp &b2, const Fp &b3) const {
+        const Fp u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);      // own components of this pair's operands
+        const Fp up = shfl_from(u, lane ^ 1), vp = shfl_from(v, lane ^ 1);      // the partner's
+        // q = 0: c0 = u0 v0 - u1 v1      q = 1: c1 = u0 v1 + u1 v0
+#if defined(__HIP_DEVICE_COMPILE__)
+        const Fp m1 = fp_mul_cols28(sel2(q, u, up), v), m2 = fp_mul_cols28(sel2(q, up, u), vp);
+#else
+        const Fp m1 = mul(sel2(q, u, up), v), m2 = mul(sel2(q, up, u), vp);      // host pass only parses this
+#endif
+        const Fp c = q ? add(m1, m2) : sub(m1, m2);
+        return Prod4c{shfl_from(c, gbase + q), shfl_from(c, gbase + 2 + q), shfl_from(c, gbase + 4 + q), shfl_from(c, gbase + 6 + q)};
+    }
+    // an Fp2 predicate holds when it holds on both components
+    __device__ __forceinline__ bool both(bool mine) const { const int m = mine ? 1 : 0; return (m & __shfl(m, lane ^ 1, 64)) != 0; }
+};
+// A point over Fp2 seen from one lane: Xyzz<Fp> / Aff<Fp> holding this lane's component of each coordinate.
+__device__ __forceinline__ Xyzz<Fp> component_of(const Xyzz<Fp2> &p, int q) {
+    return Xyzz<Fp>{sel2(q, p.x.c0, p.x.c1), sel2(q, p.y.c0, p.y.c1), sel2(q, p.zz.c0, p.zz.c1), sel2(q, p.zzz.c0, p.zzz.c1)};
+}
+__device__ __forceinline__ bool is_inf8c(const Xyzz<Fp> &p, const PairProd8 &pp) { return pp.both(is_zero(p.zz)); }
+// 2P (dbl-2008-s-1), three rounds; infinity stays infinity (zz = 0 propagates)
+__device__ __forceinline__ Xyzz<Fp> dbl8c(const Xyzz<Fp> &p, const PairProd8 &prod) {
+    const Fp U = dbl(p.y);
+    Prod4c pr = prod(U, p.x, U, U, U, p.x, U, U);
+    const Fp V = pr.r0, XX = pr.r1;
+    const Fp M = add(dbl(XX), XX);
+    pr = prod(U, p.x, M, V, V, V, M, p.zz);
+    const Fp W = pr.r0, S = pr.r1, MM = pr.r2, ZZ3 = pr.r3;
+    const Fp X3 = sub(MM, dbl(S));
+    pr = prod(M, W, W, W, sub(S, X3), p.y, p.zzz, p.zzz);
+    return Xyzz<Fp>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
+}
+// P + Q (add-2008-s), four rounds, complete
+__device__ __forceinline__ Xyzz<Fp> add8c(const Xyzz<Fp> &p, const Xyzz<Fp> &q, const PairProd8 &prod) {
+    if (is_inf8c(q, prod)) return p;                           // uniform in the group
+    if (is_inf8c(p, prod)) return q;
+    Prod4c pr = prod(p.x, q.x, p.y, q.y, q.zz, p.zz, q.zzz, p.zzz);
+    const Fp U1 = pr.r0, U2 = pr.r1, S1 = pr.r2, S2 = pr.r3;
+    const Fp Pd = sub(U2, U1), Rr = sub(S2, S1);
+    if (prod.both(is_zero(Pd))) {                              // same x: double or cancel (rare)
+        if (prod.both(is_zero(Rr))) return dbl8c(p, prod);
+        return Xyzz<Fp>{fp_zero(), fp_zero(), fp_zero(), fp_zero()};
+    }
+    pr = prod(Pd, Rr, p.zz, p.zzz, Pd, Rr, q.zz, q.zzz);
+    const Fp PP = pr.r0, RR = pr.r1, ZZ12 = pr.r2, ZZZ12 = pr.r3;
+    pr = prod(Pd, U1, ZZ12, ZZ12, PP, PP, PP, PP);
+    const Fp PPP = pr.r0, Qv = pr.r1, ZZ3 = pr.r2;
+    const Fp X3 = sub(sub(RR, PPP), dbl(Qv));
+    pr = prod(Rr, S1, ZZZ12, ZZZ12, sub(Qv, X3), PPP, PPP, PPP);
+    return Xyzz<Fp>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
+}
+__device__ __forceinline__ Xyzz<Fp> small_mul8c(const Xyzz<Fp> &p, uint32_t m, const PairProd8 &prod) {
+    Xyzz<Fp> acc{fp_zero(), fp_zero(), fp_zero(), fp_zero()};
+    for (int i = 31 - __builtin_clz(m | 1u); i >= 0; i--) {
+        acc = dbl8c(acc, prod);
+        if ((m >> i) & 1u) acc = add8c(acc, p, prod);
+    }
+    return acc;
+}
+
 }  // namespace eip

@@ -625,6 +625,72 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     }
 }
 
+// fold of lightly split G2 buckets with the 8-lane component-split addition (lanes.h)
+__global__ void __launch_bounds__(256)
+k_msm_fold_small8c(Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+                   const uint32_t *__restrict__ split_counts) {
+    const uint32_t n = split_counts[0];
+    const int lane = threadIdx.x & 63, sl = lane & 7, gb = lane & ~7, q = sl & 1;
+    const PairProd8 prod(lane, sl, gb);
+    for (uint32_t h = blockIdx.x * 32u + (threadIdx.x >> 3); h < n; h += gridDim.x * 32u) {   // uniform in the group
+        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        Xyzz<Fp> acc = component_of(partial[t0], q);
+        for (uint32_t t = t0 + 1; t < t1; t++) acc = add8c(acc, component_of(partial[t], q), prod);
+        if (sl < 2) {
+            Fp *out = reinterpret_cast<Fp *>(&partial[t0]);
+            out[0 + q] = acc.x; out[2 + q] = acc.y; out[4 + q] = acc.zz; out[6 + q] = acc.zzz;
+        }
+    }
+}
+
+// ---- G2 bucket reduce, 8 lanes per running sum, split by Fp2 component -----------------------------------
+// k_msm_reduce4<Fp2> kept whole Fp2 points replicated on 4 lanes: R, Q and the operand are 288 dwords per
+// lane, so the kernel lived in scratch (2 176 B per lane; 2.7 GB of scratch traffic per launch at 2^16
+// records, 1.3 ms).  Here a running sum owns 8 lanes and lane (p, q) holds component q only (lanes.h,
+// PairProd8): 144 dwords, products by the schoolbook rule on lane pairs, linear steps on Fp.
+// 256 threads = 32 eight-lane groups, one segment of S buckets per group.
+__global__ void __launch_bounds__(256, 1)
+k_msm_reduce8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
+               Xyzz<Fp2> *__restrict__ winout) {
+    int w;
+    uint32_t bx;
+    reduce_block_to_window(rg, pl, w, bx);
+    claim_whole_simd();                            // one wave per SIMD (lanes.h)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 7, gb = lane & ~7, q = sl & 1;
+    const PairProd8 prod(lane, sl, gb);
+    const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
+    const uint32_t seg = bx * 32u + (threadIdx.x >> 3);
+    const uint32_t lo = seg * pl.S;
+    const Xyzz<Fp> inf{fp_zero(), fp_zero(), fp_zero(), fp_zero()};
+    Xyzz<Fp> C = inf;
+    if (lo < nbw) {                                            // uniform in the group
+        const uint32_t hi = min(lo + pl.S, nbw);
+        Xyzz<Fp> R = inf, Q = inf;
+        for (uint32_t v = hi; v > lo; v--) {
+            const uint32_t g = (uint32_t)w * pl.B + v - 1u;
+            const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+            if (t1 > t0) R = add8c(R, component_of(partial[t0], q), prod);      // multi-task buckets were folded into slot t0
+            Q = add8c(Q, R, prod);
+        }
+        C = add8c(Q, small_mul8c(R, lo, prod), prod);          // sum_{v in (lo, hi]} v * B_v = Q + lo * R
+    }
+    // tree over the 8 groups of the wave, then the 4 waves through LDS
+    for (int off = 8; off < 64; off <<= 1) {
+        Xyzz<Fp> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 8) C = add8c(C, o, prod);
+    }
+    __shared__ Xyzz<Fp> sm[4][2];                  // [wave][component]
+    if (lane < 2) sm[wave][lane] = C;
+    __syncthreads();
+    if (wave == 0 && lane < 8) {
+        for (int k = 1; k < 4; k++) C = add8c(C, sm[k][q], prod);
+        if (lane < 2) {                            // lane q writes component q of every coordinate
+            Fp *out = reinterpret_cast<Fp *>(&winout[blockIdx.x]);
+            out[0 + q] = C.x; out[2 + q] = C.y; out[4 + q] = C.zz; out[6 + q] = C.zzz;
+        }
+    }
+}
+
 // ---- bucket reduce, one lane per running sum (used for G1) ------------------------------------
 // Measured at 2^20 / c = 16: 1.55 ms against 1.8-2.1 ms for the 4-lane form above (whose per-round
 // select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
@@ -689,6 +755,24 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
     hipLaunchKernelGGL(k_msm_accum2<Fp2>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
+static void launch_fold_small(hipStream_t s, bool four, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
+        hipLaunchKernelGGL(k_msm_fold_small4<Fp>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+    else
+        hipLaunchKernelGGL(k_msm_fold_small<Fp>, dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
+}
+static void launch_fold_small(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    hipLaunchKernelGGL(k_msm_fold_small8c, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+}
+static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, const Xyzz<Fp> *partial, const uint32_t *taskoff,
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout) {
+    if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+}
+static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
+    hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+}
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; static constexpr const char *kName = "eip::Fp"; };
@@ -727,7 +811,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // shorter chain wins (2^7 .. 2^16 records: 0.61 -> 0.41 ms .. 1.76 -> 1.45 ms of device time); at
     // c = 16 (557 K buckets) four lanes per segment would oversubscribe the SIMDs and lose.
     const bool four = ReduceCfg<F>::kFourLane || pl.NB <= kFourLaneMaxBuckets;
-    const uint32_t seg_per_block = four ? 64u : 256u;
+    const bool eight = ReduceCfg<F>::kFourLane;               // G2: 8 lanes per segment, split by component
+    const uint32_t seg_per_block = eight ? 32u : four ? 64u : 256u;
     // Segment length S: the shortest chain whose blocks (4 waves each, one wave per SIMD: both kernels
     // claim the whole SIMD) still fit the chip in one round -- 256 CUs x 4 SIMDs.  The grid holds
     // working blocks only, so the target is close to that limit (before: a (blocks, W) grid sized for
@@ -813,15 +898,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
     launch_accum(s, task_blocks, pl.c <= 13, pts, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
-        hipLaunchKernelGGL(k_msm_fold_small4<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
-    else
-        hipLaunchKernelGGL(k_msm_fold_small<F>, dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
+    launch_fold_small(s, four, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
-    if (four)
-        hipLaunchKernelGGL(k_msm_reduce4<F>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
-    else
-        hipLaunchKernelGGL(k_msm_reduce1<F>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    launch_reduce(s, red_blocks, four, partial, taskoff, pl, rg, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 

@@ -186,20 +186,7 @@ k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ f
 // (2^12 pairs: walk 1.43 -> 1.04 ms; 2 pairs: check 1.92 -> 1.77 ms; 2^15 pairs: 12.1 -> 10.5 ms), so it
 // is the only one left.
 struct TcFp { Fp x, y, z; };                      // this lane's component of the running point
-struct Prod4c { Fp r0, r1, r2, r3; };             // this lane's component of the four products of a round
-struct Walk8c {
-    int p, q, lane, gbase;
-    __device__ __forceinline__ Walk8c(int lane_, int sl, int gb) : p(sl >> 1), q(sl & 1), lane(lane_), gbase(gb) {}
-    __device__ __forceinline__ Prod4c operator()(const Fp &a0, const Fp &a1, const Fp &a2, const Fp &a3,
-                                                 const Fp &b0, const Fp &b1, const Fp &b2, const Fp &b3) const {
-        const Fp u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);      // own components of this pair's operands
-        const Fp up = shfl_from(u, lane ^ 1), vp = shfl_from(v, lane ^ 1);      // the partner's
-        // q = 0: c0 = u0 v0 - u1 v1      q = 1: c1 = u0 v1 + u1 v0
-        const Fp m1 = fp_mul_cols28(sel2(q, u, up), v), m2 = fp_mul_cols28(sel2(q, up, u), vp);
-        const Fp c = q ? add(m1, m2) : sub(m1, m2);
-        return Prod4c{shfl_from(c, gbase + q), shfl_from(c, gbase + 2 + q), shfl_from(c, gbase + 4 + q), shfl_from(c, gbase + 6 + q)};
-    }
-};
+using Walk8c = PairProd8;                         // lanes.h: products of a round, split by Fp2 component
 // lane pair `part` stores line coefficient `part` (a0, a1, a4), each lane its component
 __device__ __forceinline__ void store_line_part_c(LineRec *dst, int part, const Fp &v, bool contributes, const Walk8c &w) {
     if (w.p == part) {
