@@ -53,6 +53,7 @@ __device__ __forceinline__ Fp sel2(int r, const Fp &a, const Fp &b) {
     for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : b.l[i];
     return o;
 }
+__device__ __forceinline__ FpI sel2(int r, const FpI &a, const FpI &b) { return FpI{sel2(r, a.v, b.v)}; }
 __device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
     Fp2 o;
 #pragma unroll
@@ -71,64 +72,67 @@ __device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
 // lane's component of its two operands (one exchange with lane ^ 1).  A round multiplies four pairs of
 // operands: lane pair p computes product p by the schoolbook rule (c0 = a0 b0 - a1 b1,
 // c1 = a0 b1 + a1 b0: two Fp products per lane), and every lane gets its component of all four results.
-struct Prod4c { Fp r0, r1, r2, r3; };             // this lane's component of the four products of a round
+// Components are FpI values: kept in [0, 2p) (field.h), so a product needs no final conditional
+// subtraction; whatever leaves a kernel goes through fp_canon().
+struct Prod4c { FpI r0, r1, r2, r3; };            // this lane's component of the four products of a round
 struct PairProd8 {
     int p, q, lane, gbase;
     __device__ __forceinline__ PairProd8(int lane_, int sl, int gb) : p(sl >> 1), q(sl & 1), lane(lane_), gbase(gb) {}
-    __device__ __forceinline__ Prod4c operator()(const Fp &a0, const Fp &a1, const Fp &a2, const Fp &a3,
-                                                 const Fp &b0, const Fp &b1, const Fp &b2, const Fp &b3) const {
-        const Fp u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);      // own components of this pair's operands
-        const Fp up = shfl_from(u, lane ^ 1), vp = shfl_from(v, lane ^ 1);      // the partner's
+    __device__ __forceinline__ Prod4c operator()(const FpI &a0, const FpI &a1, const FpI &a2, const FpI &a3,
+                                                 const FpI &b0, const FpI &b1, const FpI &b2, const FpI &b3) const {
+        const FpI u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);     // own components of this pair's operands
+        const FpI up = shfl_from(u, lane ^ 1), vp = shfl_from(v, lane ^ 1);     // the partner's
         // q = 0: c0 = u0 v0 - u1 v1      q = 1: c1 = u0 v1 + u1 v0
-#if defined(__HIP_DEVICE_COMPILE__)
-        const Fp m1 = fp_mul_cols28(sel2(q, u, up), v), m2 = fp_mul_cols28(sel2(q, up, u), vp);
-#else
-        const Fp m1 = mul(sel2(q, u, up), v), m2 = mul(sel2(q, up, u), vp);      // host pass only parses this
-#endif
-        const Fp c = q ? add(m1, m2) : sub(m1, m2);
+        const FpI m1 = mul(sel2(q, u, up), v), m2 = mul(sel2(q, up, u), vp);
+        const FpI c = q ? add(m1, m2) : sub(m1, m2);
         return Prod4c{shfl_from(c, gbase + q), shfl_from(c, gbase + 2 + q), shfl_from(c, gbase + 4 + q), shfl_from(c, gbase + 6 + q)};
     }
     // an Fp2 predicate holds when it holds on both components
     __device__ __forceinline__ bool both(bool mine) const { const int m = mine ? 1 : 0; return (m & __shfl(m, lane ^ 1, 64)) != 0; }
 };
-// A point over Fp2 seen from one lane: Xyzz<Fp> / Aff<Fp> holding this lane's component of each coordinate.
-__device__ __forceinline__ Xyzz<Fp> component_of(const Xyzz<Fp2> &p, int q) {
-    return Xyzz<Fp>{sel2(q, p.x.c0, p.x.c1), sel2(q, p.y.c0, p.y.c1), sel2(q, p.zz.c0, p.zz.c1), sel2(q, p.zzz.c0, p.zzz.c1)};
+// A point over Fp2 seen from one lane: Xyzz<FpI> holding this lane's component of each coordinate.
+__device__ __forceinline__ Xyzz<FpI> component_of(const Xyzz<Fp2> &p, int q) {
+    return Xyzz<FpI>{FpI{sel2(q, p.x.c0, p.x.c1)}, FpI{sel2(q, p.y.c0, p.y.c1)}, FpI{sel2(q, p.zz.c0, p.zz.c1)}, FpI{sel2(q, p.zzz.c0, p.zzz.c1)}};
 }
-__device__ __forceinline__ bool is_inf8c(const Xyzz<Fp> &p, const PairProd8 &pp) { return pp.both(is_zero(p.zz)); }
+// lane q of a pair writes component q of every coordinate, canonical
+__device__ __forceinline__ void store_component(Xyzz<Fp2> *dst, const Xyzz<FpI> &p, int q) {
+    Fp *out = reinterpret_cast<Fp *>(dst);
+    out[0 + q] = fp_canon(p.x); out[2 + q] = fp_canon(p.y); out[4 + q] = fp_canon(p.zz); out[6 + q] = fp_canon(p.zzz);
+}
+__device__ __forceinline__ bool is_inf8c(const Xyzz<FpI> &p, const PairProd8 &pp) { return pp.both(is_zero(p.zz)); }
 // 2P (dbl-2008-s-1), three rounds; infinity stays infinity (zz = 0 propagates)
-__device__ __forceinline__ Xyzz<Fp> dbl8c(const Xyzz<Fp> &p, const PairProd8 &prod) {
-    const Fp U = dbl(p.y);
+__device__ __forceinline__ Xyzz<FpI> dbl8c(const Xyzz<FpI> &p, const PairProd8 &prod) {
+    const FpI U = dbl(p.y);
     Prod4c pr = prod(U, p.x, U, U, U, p.x, U, U);
-    const Fp V = pr.r0, XX = pr.r1;
-    const Fp M = add(dbl(XX), XX);
+    const FpI V = pr.r0, XX = pr.r1;
+    const FpI M = add(dbl(XX), XX);
     pr = prod(U, p.x, M, V, V, V, M, p.zz);
-    const Fp W = pr.r0, S = pr.r1, MM = pr.r2, ZZ3 = pr.r3;
-    const Fp X3 = sub(MM, dbl(S));
+    const FpI W = pr.r0, S = pr.r1, MM = pr.r2, ZZ3 = pr.r3;
+    const FpI X3 = sub(MM, dbl(S));
     pr = prod(M, W, W, W, sub(S, X3), p.y, p.zzz, p.zzz);
-    return Xyzz<Fp>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
+    return Xyzz<FpI>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
 }
 // P + Q (add-2008-s), four rounds, complete
-__device__ __forceinline__ Xyzz<Fp> add8c(const Xyzz<Fp> &p, const Xyzz<Fp> &q, const PairProd8 &prod) {
+__device__ __forceinline__ Xyzz<FpI> add8c(const Xyzz<FpI> &p, const Xyzz<FpI> &q, const PairProd8 &prod) {
     if (is_inf8c(q, prod)) return p;                           // uniform in the group
     if (is_inf8c(p, prod)) return q;
     Prod4c pr = prod(p.x, q.x, p.y, q.y, q.zz, p.zz, q.zzz, p.zzz);
-    const Fp U1 = pr.r0, U2 = pr.r1, S1 = pr.r2, S2 = pr.r3;
-    const Fp Pd = sub(U2, U1), Rr = sub(S2, S1);
+    const FpI U1 = pr.r0, U2 = pr.r1, S1 = pr.r2, S2 = pr.r3;
+    const FpI Pd = sub(U2, U1), Rr = sub(S2, S1);
     if (prod.both(is_zero(Pd))) {                              // same x: double or cancel (rare)
         if (prod.both(is_zero(Rr))) return dbl8c(p, prod);
-        return Xyzz<Fp>{fp_zero(), fp_zero(), fp_zero(), fp_zero()};
+        return xyzz_inf<FpI>();
     }
     pr = prod(Pd, Rr, p.zz, p.zzz, Pd, Rr, q.zz, q.zzz);
-    const Fp PP = pr.r0, RR = pr.r1, ZZ12 = pr.r2, ZZZ12 = pr.r3;
+    const FpI PP = pr.r0, RR = pr.r1, ZZ12 = pr.r2, ZZZ12 = pr.r3;
     pr = prod(Pd, U1, ZZ12, ZZ12, PP, PP, PP, PP);
-    const Fp PPP = pr.r0, Qv = pr.r1, ZZ3 = pr.r2;
-    const Fp X3 = sub(sub(RR, PPP), dbl(Qv));
+    const FpI PPP = pr.r0, Qv = pr.r1, ZZ3 = pr.r2;
+    const FpI X3 = sub(sub(RR, PPP), dbl(Qv));
     pr = prod(Rr, S1, ZZZ12, ZZZ12, sub(Qv, X3), PPP, PPP, PPP);
-    return Xyzz<Fp>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
+    return Xyzz<FpI>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
 }
-__device__ __forceinline__ Xyzz<Fp> small_mul8c(const Xyzz<Fp> &p, uint32_t m, const PairProd8 &prod) {
-    Xyzz<Fp> acc{fp_zero(), fp_zero(), fp_zero(), fp_zero()};
+__device__ __forceinline__ Xyzz<FpI> small_mul8c(const Xyzz<FpI> &p, uint32_t m, const PairProd8 &prod) {
+    Xyzz<FpI> acc = xyzz_inf<FpI>();
     for (int i = 31 - __builtin_clz(m | 1u); i >= 0; i--) {
         acc = dbl8c(acc, prod);
         if ((m >> i) & 1u) acc = add8c(acc, p, prod);

@@ -634,12 +634,9 @@ k_msm_fold_small8c(Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict__
     const PairProd8 prod(lane, sl, gb);
     for (uint32_t h = blockIdx.x * 32u + (threadIdx.x >> 3); h < n; h += gridDim.x * 32u) {   // uniform in the group
         const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
-        Xyzz<Fp> acc = component_of(partial[t0], q);
+        Xyzz<FpI> acc = component_of(partial[t0], q);
         for (uint32_t t = t0 + 1; t < t1; t++) acc = add8c(acc, component_of(partial[t], q), prod);
-        if (sl < 2) {
-            Fp *out = reinterpret_cast<Fp *>(&partial[t0]);
-            out[0 + q] = acc.x; out[2 + q] = acc.y; out[4 + q] = acc.zz; out[6 + q] = acc.zzz;
-        }
+        if (sl < 2) store_component(&partial[t0], acc, q);
     }
 }
 
@@ -661,11 +658,11 @@ k_msm_reduce8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict
     const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
     const uint32_t seg = bx * 32u + (threadIdx.x >> 3);
     const uint32_t lo = seg * pl.S;
-    const Xyzz<Fp> inf{fp_zero(), fp_zero(), fp_zero(), fp_zero()};
-    Xyzz<Fp> C = inf;
+    const Xyzz<FpI> inf = xyzz_inf<FpI>();
+    Xyzz<FpI> C = inf;
     if (lo < nbw) {                                            // uniform in the group
         const uint32_t hi = min(lo + pl.S, nbw);
-        Xyzz<Fp> R = inf, Q = inf;
+        Xyzz<FpI> R = inf, Q = inf;
         for (uint32_t v = hi; v > lo; v--) {
             const uint32_t g = (uint32_t)w * pl.B + v - 1u;
             const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
@@ -676,18 +673,15 @@ k_msm_reduce8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict
     }
     // tree over the 8 groups of the wave, then the 4 waves through LDS
     for (int off = 8; off < 64; off <<= 1) {
-        Xyzz<Fp> o = shfl_from(C, (lane + off) & 63);
+        Xyzz<FpI> o = shfl_from(C, (lane + off) & 63);
         if ((lane & (2 * off - 1)) < 8) C = add8c(C, o, prod);
     }
-    __shared__ Xyzz<Fp> sm[4][2];                  // [wave][component]
+    __shared__ Xyzz<FpI> sm[4][2];                  // [wave][component]
     if (lane < 2) sm[wave][lane] = C;
     __syncthreads();
     if (wave == 0 && lane < 8) {
         for (int k = 1; k < 4; k++) C = add8c(C, sm[k][q], prod);
-        if (lane < 2) {                            // lane q writes component q of every coordinate
-            Fp *out = reinterpret_cast<Fp *>(&winout[blockIdx.x]);
-            out[0 + q] = C.x; out[2 + q] = C.y; out[4 + q] = C.zz; out[6 + q] = C.zzz;
-        }
+        if (lane < 2) store_component(&winout[blockIdx.x], C, q);
     }
 }
 

@@ -56,56 +56,51 @@ struct LineRec { Fp2 a0, a1, a4; };      // l = a0 + a1 v + a4 v w   (a1, a4 alr
 // pair made that 1.5-1.8 ms of serial products -- the critical path of every batch below ~2000 pairs
 // once the line walk got shorter.  Here a pair owns 4 lanes: the independent Fp products of an
 // XYZZ doubling (3 rounds) or addition (4 rounds) go one per lane and are exchanged by shuffles.
-__device__ __forceinline__ Fp g1mul(const Fp &a, const Fp &b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return fp_mul_cols28(a, b);
-#else
-    return mul(a, b);
-#endif
-}
+// (values are FpI: kept in [0, 2p), no conditional subtraction after a product -- field.h)
 // P + Q (add-2008-s), operands replicated on the 4 lanes of the group, complete
-__device__ __forceinline__ Xyzz<Fp> g1_add4(const Xyzz<Fp> &p, const Xyzz<Fp> &q, int r, int gb) {
+__device__ __forceinline__ Xyzz<FpI> g1_add4(const Xyzz<FpI> &p, const Xyzz<FpI> &q, int r, int gb) {
     if (is_inf(q)) return p;                                  // uniform in the group
     if (is_inf(p)) return q;
-    Fp pr = g1mul(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
-    const Fp U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
-    const Fp Pd = sub(U2, U1), Rr = sub(S2, S1);
+    FpI pr = mul(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
+    const FpI U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
+    const FpI Pd = sub(U2, U1), Rr = sub(S2, S1);
     if (is_zero(Pd)) {                                        // same x: double or cancel (small-order inputs)
         if (is_zero(Rr)) return dbl(p);
-        return xyzz_inf<Fp>();
+        return xyzz_inf<FpI>();
     }
-    pr = g1mul(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
-    const Fp PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
-    pr = g1mul(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
-    const Fp PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
-    const Fp X3 = sub(sub(RR, PPP), dbl(Q));
-    pr = g1mul(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
-    const Fp t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
-    return Xyzz<Fp>{X3, sub(t0, t1), ZZ3, ZZZ3};
+    pr = mul(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
+    const FpI PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
+    pr = mul(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
+    const FpI PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
+    const FpI X3 = sub(sub(RR, PPP), dbl(Q));
+    pr = mul(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
+    const FpI t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    return Xyzz<FpI>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // 2P (dbl-2008-s-1); infinity stays infinity (zz = 0 propagates)
-__device__ __forceinline__ Xyzz<Fp> g1_dbl4(const Xyzz<Fp> &p, int r, int gb) {
-    const Fp U = dbl(p.y);
-    Fp pr = g1mul(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
-    const Fp V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
-    const Fp M = add(dbl(XX), XX);
-    pr = g1mul(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
-    const Fp W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
-    const Fp X3 = sub(MM, dbl(S));
-    pr = g1mul(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
-    const Fp t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
-    return Xyzz<Fp>{X3, sub(t0, t1), ZZ3, ZZZ3};
+__device__ __forceinline__ Xyzz<FpI> g1_dbl4(const Xyzz<FpI> &p, int r, int gb) {
+    const FpI U = dbl(p.y);
+    FpI pr = mul(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
+    const FpI V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
+    const FpI M = add(dbl(XX), XX);
+    pr = mul(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
+    const FpI W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
+    const FpI X3 = sub(MM, dbl(S));
+    pr = mul(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
+    const FpI t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    return Xyzz<FpI>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // [|z|]p on the 4 lanes of the group
-__device__ __forceinline__ Xyzz<Fp> g1_mul_zabs4(const Xyzz<Fp> &p, int r, int gb) {
+__device__ __forceinline__ Xyzz<FpI> g1_mul_zabs4(const Xyzz<FpI> &p, int r, int gb) {
     const uint64_t z = K_Z_ABS;
-    Xyzz<Fp> acc = p;
+    Xyzz<FpI> acc = p;
     for (int i = 62; i >= 0; i--) {
         acc = g1_dbl4(acc, r, gb);
         if ((z >> i) & 1ull) acc = g1_add4(acc, p, r, gb);
     }
     return acc;
 }
+
 // Coalesced batches (several small calls' pairs back to back, api.hip): every call has its own
 // first-error word; pair i belongs to the call j with coff[j] <= i < coff[j + 1].  A single call is the
 // map with M = 1 (no table).
@@ -160,11 +155,12 @@ k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ f
     if (EXCL) claim_whole_simd();
     if (i >= k) return;                                       // uniform in the group
     if (!flagP[i]) return;                                    // infinity (a member) or already reported by the decode
-    const Aff<Fp> p = pmont[i];
+    const Aff<Fp> pc = pmont[i];
+    const Aff<FpI> p{FpI{pc.x}, FpI{pc.y}};
     // phi(P) == -[z^2]P  (curve.h in_g1)
-    const Xyzz<Fp> t = g1_mul_zabs4(g1_mul_zabs4(from_affine(p), r, gb), r, gb);
-    const Aff<Fp> phi_neg{g1mul(p.x, Fp{{K_BETA}}), neg(p.y)};
-    const bool same = !is_inf(t) && eq(g1mul(phi_neg.x, t.zz), t.x) && eq(g1mul(phi_neg.y, t.zzz), t.y);
+    const Xyzz<FpI> t = g1_mul_zabs4(g1_mul_zabs4(from_affine(p), r, gb), r, gb);
+    const Aff<FpI> phi_neg{mul(p.x, FpI{Fp{{K_BETA}}}), neg(p.y)};
+    const bool same = !is_inf(t) && eq(mul(phi_neg.x, t.zz), t.x) && eq(mul(phi_neg.y, t.zzz), t.y);
     if (!same && r == 0) report_pair_error(err, cm, i, (unsigned long long)E_NOT_IN_SUBGROUP);
 }
 
@@ -185,25 +181,25 @@ k_pair_check_g1(const Aff<Fp> *__restrict__ pmont, const uint8_t *__restrict__ f
 // pairs; this form is ~5 500 without spills to memory, and faster than each of the three at every size
 // (2^12 pairs: walk 1.43 -> 1.04 ms; 2 pairs: check 1.92 -> 1.77 ms; 2^15 pairs: 12.1 -> 10.5 ms), so it
 // is the only one left.
-struct TcFp { Fp x, y, z; };                      // this lane's component of the running point
+struct TcFp { FpI x, y, z; };                     // this lane's component of the running point, in [0, 2p)
 using Walk8c = PairProd8;                         // lanes.h: products of a round, split by Fp2 component
 // lane pair `part` stores line coefficient `part` (a0, a1, a4), each lane its component
-__device__ __forceinline__ void store_line_part_c(LineRec *dst, int part, const Fp &v, bool contributes, const Walk8c &w) {
-    if (w.p == part) {
+__device__ __forceinline__ void store_line_part_c(LineRec *dst, int part, const FpI &v, bool contributes, const Walk8c &w) {
+    if (w.p == part) {                      // canonical in memory: the product tree computes in [0, p)
         Fp *slot = reinterpret_cast<Fp *>(&dst->a0) + 2 * part + w.q;
-        *slot = contributes ? v : ((part == 0 && w.q == 0) ? fp_one() : fp_zero());
+        *slot = contributes ? fp_canon(v) : ((part == 0 && w.q == 0) ? fp_one() : fp_zero());
     }
 }
 __device__ __forceinline__ void miller_dbl_step_c(TcFp &T, const Walk8c &prod, LineRec *dst, bool contributes) {
     Prod4c pr = prod(T.x, T.y, T.z, T.y, T.x, T.y, T.z, T.z);
-    const Fp A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
-    const Fp E = add(dbl(A), A), XB = add(T.x, B);
+    const FpI A = pr.r0, B = pr.r1, ZZ = pr.r2, YZ = pr.r3;
+    const FpI E = add(dbl(A), A), XB = add(T.x, B);
     pr = prod(B, XB, E, E, B, XB, E, T.x);
-    const Fp C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
+    const FpI C = pr.r0, t = pr.r1, F = pr.r2, EX = pr.r3;
     store_line_part_c(dst, 0, sub(EX, dbl(B)), contributes, prod);              // 3X^3 - 2Y^2
-    const Fp D = dbl(sub(sub(t, A), C));
-    const Fp X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
-    const Fp C8 = dbl(dbl(dbl(C)));
+    const FpI D = dbl(sub(sub(t, A), C));
+    const FpI X3 = sub(F, dbl(D)), Z3 = dbl(YZ);
+    const FpI C8 = dbl(dbl(dbl(C)));
     pr = prod(E, Z3, E, E, ZZ, ZZ, sub(D, X3), ZZ);
     store_line_part_c(dst, 1, neg(pr.r0), contributes, prod);                   // -3X^2 Z^2
     store_line_part_c(dst, 2, pr.r1, contributes, prod);                        // 2YZ^3
@@ -211,20 +207,20 @@ __device__ __forceinline__ void miller_dbl_step_c(TcFp &T, const Walk8c &prod, L
     T.y = sub(pr.r2, C8);
     T.z = Z3;
 }
-__device__ __forceinline__ void miller_add_step_c(TcFp &T, const Fp &Qx, const Fp &Qy, const Walk8c &prod, LineRec *dst, bool contributes) {
+__device__ __forceinline__ void miller_add_step_c(TcFp &T, const FpI &Qx, const FpI &Qy, const Walk8c &prod, LineRec *dst, bool contributes) {
     Prod4c pr = prod(T.z, T.z, T.z, T.z, T.z, T.z, T.z, T.z);
-    const Fp ZZ = pr.r0;
+    const FpI ZZ = pr.r0;
     pr = prod(Qx, ZZ, Qx, Qx, ZZ, T.z, ZZ, ZZ);
-    const Fp U2 = pr.r0, ZZZ = pr.r1;
+    const FpI U2 = pr.r0, ZZZ = pr.r1;
     pr = prod(Qy, Qy, Qy, Qy, ZZZ, ZZZ, ZZZ, ZZZ);
-    const Fp S2 = pr.r0;
-    const Fp H = sub(U2, T.x), th = sub(S2, T.y);
+    const FpI S2 = pr.r0;
+    const FpI H = sub(U2, T.x), th = sub(S2, T.y);
     pr = prod(H, T.z, th, th, H, H, th, Qx);
-    const Fp HH = pr.r0, Z3 = pr.r1, TH2 = pr.r2, thQx = pr.r3;
+    const FpI HH = pr.r0, Z3 = pr.r1, TH2 = pr.r2, thQx = pr.r3;
     pr = prod(HH, T.x, Z3, HH, H, HH, Qy, H);
-    const Fp HHH = pr.r0, V = pr.r1, Z3Qy = pr.r2;
-    const Fp X3 = sub(sub(TH2, HHH), dbl(V));
-    const Fp VX = sub(V, X3);
+    const FpI HHH = pr.r0, V = pr.r1, Z3Qy = pr.r2;
+    const FpI X3 = sub(sub(TH2, HHH), dbl(V));
+    const FpI VX = sub(V, X3);
     pr = prod(th, T.y, th, th, VX, HHH, VX, VX);
     store_line_part_c(dst, 0, sub(thQx, Z3Qy), contributes, prod);
     store_line_part_c(dst, 1, neg(th), contributes, prod);
@@ -247,7 +243,7 @@ __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, 
         contributes = q_live && flagP[i] != 0;                   // else the pair contributes 1
         const Aff<Fp2> Q = qmont[i];
         if (sl == 0) sQ[gi] = Q;
-        T = TcFp{sel2(q, Q.x.c0, Q.x.c1), sel2(q, Q.y.c0, Q.y.c1), q ? fp_zero() : fp_one()};
+        T = TcFp{FpI{sel2(q, Q.x.c0, Q.x.c1)}, FpI{sel2(q, Q.y.c0, Q.y.c1)}, FpI{q ? fp_zero() : fp_one()}};
     }
     __syncthreads();
     if (i >= k) return;
@@ -265,19 +261,19 @@ __device__ __forceinline__ void pair_walk8c(const Aff<Fp2> *__restrict__ qmont, 
         miller_dbl_step_c(T, prod, &lines[(size_t)s * k + i], contributes);
         s++;
         if ((z >> bit) & 1ull) {              // 5 of 63 steps
-            const Fp Qx = q ? sQ[gi].x.c1 : sQ[gi].x.c0, Qy = q ? sQ[gi].y.c1 : sQ[gi].y.c0;
+            const FpI Qx{q ? sQ[gi].x.c1 : sQ[gi].x.c0}, Qy{q ? sQ[gi].y.c1 : sQ[gi].y.c0};
             miller_add_step_c(T, Qx, Qy, prod, &lines[(size_t)s * k + i], contributes);
             s++;
         }
     }
     // T = [|z|]Q (Jacobian).  Q in G2  <=>  psi(Q) == [z]Q = -T:  psi(Q).x Z^2 == X  and  -psi(Q).y Z^3 == Y
-    const Fp Qx = q ? sQ[gi].x.c1 : sQ[gi].x.c0, Qy = q ? sQ[gi].y.c1 : sQ[gi].y.c0;
-    const Fp cx = q ? neg(Qx) : Qx, cy = q ? neg(Qy) : Qy;                      // conj: component 1 negated
-    const Fp kx = q ? Fp{{K_PSI_X_C1}} : Fp{{K_PSI_X_C0}}, ky = q ? Fp{{K_PSI_Y_C1}} : Fp{{K_PSI_Y_C0}};
+    const FpI Qx{q ? sQ[gi].x.c1 : sQ[gi].x.c0}, Qy{q ? sQ[gi].y.c1 : sQ[gi].y.c0};
+    const FpI cx = q ? neg(Qx) : Qx, cy = q ? neg(Qy) : Qy;                      // conj: component 1 negated
+    const FpI kx{q ? Fp{{K_PSI_X_C1}} : Fp{{K_PSI_X_C0}}}, ky{q ? Fp{{K_PSI_Y_C1}} : Fp{{K_PSI_Y_C0}}};
     Prod4c pr = prod(cx, cy, T.z, cx, kx, ky, T.z, kx);
-    const Fp px = pr.r0, py = neg(pr.r1), zz = pr.r2;
+    const FpI px = pr.r0, py = neg(pr.r1), zz = pr.r2;
     pr = prod(px, zz, px, px, zz, T.z, zz, zz);
-    const Fp lhs_x = pr.r0, zzz = pr.r1;
+    const FpI lhs_x = pr.r0, zzz = pr.r1;
     pr = prod(py, py, py, py, zzz, zzz, zzz, zzz);
     int same = (eq(lhs_x, T.x) && eq(pr.r0, T.y)) ? 1 : 0, zzero = is_zero(T.z) ? 1 : 0;
     same &= __shfl(same, lane ^ 1, 64);                                         // both components
