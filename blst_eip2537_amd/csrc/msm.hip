@@ -390,8 +390,8 @@ template <class T> __device__ __forceinline__ Xyzz<T> madd2(const Xyzz<T> &p, co
     const T t0 = shfl_from(pr, gb), ZZZ3 = shfl_from(pr, gb + 1);
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
-// G2 always; G1 for the plans whose accumulate is a chain rather than a stream (c <= 13, up to 2^17
-// records: the longest task, not the product rate, sets its time)
+// G1 for the plans whose accumulate is a chain rather than a stream (c <= 13, up to 2^17 records: the
+// longest task, not the product rate, sets its time); G2 takes the component-split form below
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_accum2(const Aff<F> *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
@@ -409,6 +409,80 @@ k_msm_accum2(const Aff<F> *__restrict__ pts, const uint32_t *__restrict__ entrie
         acc = madd2(acc, p, r, gb);
     }
     if (r == 0) partial[t] = acc;
+}
+
+// ---- G2 accumulate, 2 lanes per task, split by Fp2 component --------------------------------------
+// k_msm_accum2 over Fp2 kept whole Fp2 values replicated on both lanes of a task (256 VGPR + 68 AGPR + spills,
+// one wave per SIMD, 70 % VALU-active: 1.19 ms at 2^16 records; this form 0.91 ms).  Here lane q of the task holds only COMPONENT q of the running
+// sum and of the loaded point -- half the registers, linear steps on Fp -- and a round still multiplies
+// two pairs of Fp2 operands, lane r computing product r whole by Karatsuba (3 Fp products): before the
+// product each lane sends its component of the OTHER lane's operands, after it the other lane's
+// component of its result (three one-element exchanges with lane ^ 1 per round).  Values are FpI: kept in
+// [0, 2p).  Same formulas and case analysis as madd2.
+struct Pair2c { FpI r0, r1; };                    // this lane's component of the two products of a round
+__device__ __forceinline__ Pair2c prod2c(const FpI &a0, const FpI &b0, const FpI &a1, const FpI &b1, int r, int lane) {
+    // my product is (a_r, b_r); the partner needs my component of (a_{1-r}, b_{1-r})
+    const FpI mine_u = sel2(r, a0, a1), mine_v = sel2(r, b0, b1);
+    const FpI other_u = shfl_from(sel2(r, a1, a0), lane ^ 1), other_v = shfl_from(sel2(r, b1, b0), lane ^ 1);
+    // lane r holds component r: (u0, u1) = r ? (other, mine) : (mine, other)
+    const FpI u0 = sel2(r, mine_u, other_u), u1 = sel2(r, other_u, mine_u);
+    const FpI v0 = sel2(r, mine_v, other_v), v1 = sel2(r, other_v, mine_v);
+    const FpI t0 = mul(u0, v0), t1 = mul(u1, v1), t2 = mul(add(u0, u1), add(v0, v1));
+    const FpI c0 = sub(t0, t1), c1 = sub(sub(t2, t0), t1);
+    // keep my component of my product, fetch my component of the partner's product
+    const FpI keep = sel2(r, c0, c1), got = shfl_from(sel2(r, c1, c0), lane ^ 1);
+    return Pair2c{sel2(r, keep, got), sel2(r, got, keep)};
+}
+__device__ __forceinline__ bool both2(bool mine, int lane) { const int m = mine ? 1 : 0; return (m & __shfl(m, lane ^ 1, 64)) != 0; }
+// 2Q for affine Q != infinity (mdbl-2008-s-1), components
+__device__ __forceinline__ Xyzz<FpI> dbl_affine2c(const Aff<FpI> &a, int r, int lane) {
+    const FpI U = dbl(a.y);
+    Pair2c pr = prod2c(U, U, a.x, a.x, r, lane);
+    const FpI V = pr.r0, XX = pr.r1;
+    const FpI M = add(dbl(XX), XX);
+    pr = prod2c(U, V, a.x, V, r, lane);
+    const FpI W = pr.r0, S = pr.r1;
+    pr = prod2c(M, M, W, a.y, r, lane);
+    const FpI X3 = sub(pr.r0, dbl(S)), Wy = pr.r1;
+    pr = prod2c(M, sub(S, X3), M, M, r, lane);
+    return Xyzz<FpI>{X3, sub(pr.r0, Wy), V, W};
+}
+__device__ __forceinline__ Xyzz<FpI> madd2c(const Xyzz<FpI> &p, const Aff<FpI> &q, int r, int lane) {
+    if (both2(is_zero(q.x) && is_zero(q.y), lane)) return p;                     // uniform in the pair of lanes
+    if (both2(is_zero(p.zz), lane)) return Xyzz<FpI>{q.x, q.y, FpI{r ? fp_zero() : fp_one()}, FpI{r ? fp_zero() : fp_one()}};
+    Pair2c pr = prod2c(q.x, p.zz, q.y, p.zzz, r, lane);
+    const FpI Pd = sub(pr.r0, p.x), Rr = sub(pr.r1, p.y);
+    if (both2(is_zero(Pd), lane)) {
+        if (both2(is_zero(Rr), lane)) return dbl_affine2c(q, r, lane);
+        return xyzz_inf<FpI>();
+    }
+    pr = prod2c(Pd, Pd, Rr, Rr, r, lane);
+    const FpI PP = pr.r0, RR = pr.r1;
+    pr = prod2c(Pd, PP, p.x, PP, r, lane);
+    const FpI PPP = pr.r0, Q = pr.r1;
+    const FpI X3 = sub(sub(RR, PPP), dbl(Q));
+    pr = prod2c(p.zz, PP, p.y, PPP, r, lane);
+    const FpI ZZ3 = pr.r0, t1 = pr.r1;
+    pr = prod2c(Rr, sub(Q, X3), p.zzz, PPP, r, lane);
+    return Xyzz<FpI>{X3, sub(pr.r0, t1), ZZ3, pr.r1};
+}
+__global__ void __launch_bounds__(256)
+k_msm_accum2c(const Aff<Fp2> *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
+              const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp2> *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, r = lane & 1;
+    const uint32_t slot = blockIdx.x * 128u + (threadIdx.x >> 1);
+    if (slot >= totals[1]) return;                             // uniform in the pair
+    const uint32_t t = perm[slot];
+    const Task tk = tasks[t];
+    Xyzz<FpI> acc = xyzz_inf<FpI>();
+    for (uint32_t e = 0; e < tk.len; e++) {
+        const uint32_t ent = entries[tk.start + e];
+        const Fp *pc = reinterpret_cast<const Fp *>(&pts[ent >> 1]);            // x.c0 x.c1 y.c0 y.c1
+        Aff<FpI> p{FpI{pc[r]}, FpI{pc[2 + r]}};
+        if (ent & 1u) p.y = neg(p.y);
+        acc = madd2c(acc, p, r, lane);
+    }
+    store_component(&partial[t], acc, r);
 }
 
 // field type the accumulate loop computes in: Fp -> FpI (inlined products), Fp2 unchanged
@@ -747,7 +821,7 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, 
 }
 static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp2> *pts, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
-    hipLaunchKernelGGL(k_msm_accum2<Fp2>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    hipLaunchKernelGGL(k_msm_accum2c, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
 static void launch_fold_small(hipStream_t s, bool four, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
     if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
@@ -864,7 +938,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     {
         const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
         LastPlan lp{};
-        snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
+        if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");        // G2: split by component
+        else snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
         lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB;
         e->last_plan = lp;
     }
@@ -1070,7 +1145,8 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     {
         LastPlan lp{};
-        snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2<%s>", ReduceCfg<F>::kName);
+        if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");
+        else snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2<%s>", ReduceCfg<F>::kName);
         lp.c = pl.c; lp.windows = pl.W; lp.lanes = 2; lp.units = (uint32_t)n; lp.buckets = pl.NB;
         e->last_plan = lp;
     }
@@ -1091,9 +1167,9 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    hipLaunchKernelGGL(k_msm_accum2<F>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    launch_accum(s, task_blocks, true, pts, entries, tasks, perm, totals, partial);      // two lanes per task
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL(k_msm_fold_small4<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_small, totals + 2);
+    launch_fold_small(s, true, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
     if (units * 4u <= 1024u)       // one block per unit while 4 waves per unit fit one round of one wave per SIMD
         hipLaunchKernelGGL((k_msm_reduce_batch<F, 4>), dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
