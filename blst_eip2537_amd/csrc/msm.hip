@@ -47,8 +47,12 @@ struct Task { uint32_t start, len; };
 // There the widths whose top window needs no merging (c = 5, 8, 13, 16 leave 6/8/9/16 top bits)
 // win by 15-25 % over their neighbours.
 static int msm_measured_width(uint32_t n, bool g2) {
-    if (n < 2048) return 8;
-    if (g2) return n <= (1u << 17) ? 13 : 0;      // larger G2 inputs: not measured, use the model
+    // round 2 re-sweep with the current kernels (profiles/r02_window_sweep.txt): c = 11 takes the band
+    // between the small and the mid plans (G1 2^12: 0.83 against 0.90 ms; G2 2^12: 1.64 against 1.93 ms),
+    // and G2 keeps c = 13 up to 2^18 records (5.7 against 6.0 ms for the work model's choice)
+    if (n <= 2048) return 8;
+    if (n <= 8192) return 11;
+    if (g2) return n <= (1u << 18) ? 13 : 0;      // larger G2 inputs: not measured, use the model
     return n <= (1u << 17) ? 13 : 16;
 }
 MsmPlan msm_make_plan(uint32_t n, int c_override, bool g2) {
