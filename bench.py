@@ -186,8 +186,8 @@ def split_child(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["g1msm", "g2msm", "pairing"], default="g1msm")
     ap.add_argument("--log2n", type=int, default=None, help="log2 of the batch (default 20 / 16 / 12)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
