@@ -37,11 +37,22 @@ def pools(rng):
     g2 += [m.ec_neg(m.FP2, p) for p in g2] + [None, m.random_g2(prng, False)]
     ks = [0, 1, 2, 3, 255, 256, 257, 0x8000, 0x8001, 0xffff, 0x10000, 0x10001, m.R - 1, m.R, m.R + 1, 2 ** 255, 2 ** 256 - 1,
           (1 << 128) + 1, rng.randrange(1 << 256), rng.randrange(1 << 256)]
+    if MID:                                           # enough distinct scalars that most buckets of a window are hit
+        ks += [rng.randrange(1 << 256) for _ in range(40)]
     return [m.encode_g1(p) for p in g1], [m.encode_g2(p) for p in g2], [m.encode_scalar(k) for k in ks]
+
+
+MID = False
 
 
 def gen_case(rng, e1, e2, ks):
     kind = rng.random()
+    if MID:                                           # the c = 11 / c = 13 plans: split buckets, folds, 4- and 8-lane reduces
+        if kind < 0.6:
+            n = rng.choice([2049, 2500, 4096, 7000, 8192, 8193, 12000, 20000])
+            return "bls12_g1multiexp", X.g1_multiexp, b"".join(rng.choice(e1) + rng.choice(ks) for _ in range(n))
+        n = rng.choice([2049, 2500, 4096, 6000, 8193])
+        return "bls12_g2multiexp", X.g2_multiexp, b"".join(rng.choice(e2) + rng.choice(ks) for _ in range(n))
     if kind < 0.45:
         n = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 31, 64, 65, 129, 300, 513, 600])
         return "bls12_g1multiexp", X.g1_multiexp, b"".join(rng.choice(e1) + rng.choice(ks) for _ in range(n))
@@ -61,7 +72,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mid", action="store_true", help="mid-size MSMs (2 049 .. 20 000 records) instead of small calls")
     args = ap.parse_args()
+    global MID
+    MID = args.mid
     stop = time.time() + args.seconds
     lock = threading.Lock()
     stats = {"cases": 0, "bad": [], "by_op": {}, "errors_seen": {}}
