@@ -890,12 +890,16 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // working blocks only, so the target is close to that limit (before: a (blocks, W) grid sized for
     // the top window, half of it idle, and ~140 working blocks: 2^20 reduce 1.42 ms, S = 16).
     static const uint32_t env_rb = [] { const char *v = getenv("EIP2537_REDUCE_BLOCKS"); return v ? (uint32_t)atoi(v) : 0u; }();
-    const uint32_t block_target = env_rb ? env_rb : (four ? 232u : 240u);
+    const uint32_t block_target = env_rb ? env_rb : (four ? 232u : 250u);
     pl.S = std::max(four ? 1u : 2u, (pl.NB + seg_per_block * block_target - 1u) / (seg_per_block * block_target));
     ReduceGrid rg;
-    rg.bn = ((pl.B + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
-    rg.bt = ((pl.BT + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
-    const uint32_t red_blocks = (uint32_t)(pl.W - 1) * rg.bn + rg.bt;
+    uint32_t red_blocks;
+    for (;; pl.S++) {                          // per-window rounding can push the grid past one wave per SIMD: lengthen S then
+        rg.bn = ((pl.B + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
+        rg.bt = ((pl.BT + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
+        red_blocks = (uint32_t)(pl.W - 1) * rg.bn + rg.bt;
+        if (red_blocks <= 256u || env_rb || pl.S >= 4096u) break;
+    }
     const size_t nwin_out = red_blocks;
 
     HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
