@@ -296,19 +296,30 @@ k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices,
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
-            uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts) {
-    uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= NB) return;
-    uint32_t cnt = counts[g];
-    if (!cnt) return;
-    uint32_t t0 = taskoff[g], off = offsets[g];
-    const uint32_t L = 1u << lshift;
-    // buckets split into several tasks are folded back into one partial before the reduce:
-    // 2..8 tasks by one thread (k_msm_fold_small), more by one block (k_msm_fold_big)
-    if (cnt > 8u * L) split_big[atomicAdd(&split_counts[1], 1u)] = g;
-    else if (cnt > L) split_small[atomicAdd(&split_counts[0], 1u)] = g;
-    for (uint32_t done = 0, j = 0; done < cnt; done += L, j++)
-        tasks[t0 + j] = Task{off + done, min(L, cnt - done)};
+            uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts,
+            uint32_t *__restrict__ lenhist, uint32_t gshift) {
+    // also the histogram of task length classes ceil(len / 2^gshift) in [1, 64] for the sort below (a
+    // separate pass over the task array before: 0.03 ms at 2^20)
+    __shared__ uint32_t h[65];
+    if (threadIdx.x < 65) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t cnt = g < NB ? counts[g] : 0u;
+    if (cnt) {
+        const uint32_t t0 = taskoff[g], off = offsets[g];
+        const uint32_t L = 1u << lshift, gm = (1u << gshift) - 1u;
+        // buckets split into several tasks are folded back into one partial before the reduce:
+        // 2..8 tasks by one thread (k_msm_fold_small), more by one block (k_msm_fold_big)
+        if (cnt > 8u * L) split_big[atomicAdd(&split_counts[1], 1u)] = g;
+        else if (cnt > L) split_small[atomicAdd(&split_counts[0], 1u)] = g;
+        const uint32_t full = cnt >> lshift, rest = cnt & (L - 1u);
+        for (uint32_t j = 0; j < full; j++) tasks[t0 + j] = Task{off + (j << lshift), L};
+        if (rest) tasks[t0 + full] = Task{off + (full << lshift), rest};
+        if (full) atomicAdd(&h[(L + gm) >> gshift], full);
+        if (rest) atomicAdd(&h[(rest + gm) >> gshift], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 65 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
 }
 
 
@@ -316,16 +327,6 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
 // a wave of k_msm_accum runs for the longest of its 64 tasks (~70 % lane utilisation at 2^20).
 // Counting sort on the length class ceil(len / (L/64)) in [1, 64]: per-block LDS histogram -> 64 global counters -> a one-wave
 // scan -> per-block range reservation -> permutation.
-__global__ void __launch_bounds__(256)
-k_msm_task_hist(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenhist, uint32_t gshift) {
-    __shared__ uint32_t h[65];
-    if (threadIdx.x < 65) h[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t < totals[1]) atomicAdd(&h[(tasks[t].len + (1u << gshift) - 1u) >> gshift], 1u);   // length class 1..64
-    __syncthreads();
-    if (threadIdx.x < 65 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
-}
 __global__ void __launch_bounds__(64)
 k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ lenoff) {
     // lane i owns length 64 - i (longest first); exclusive prefix over lanes
@@ -966,9 +967,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2);
+                       split_small, split_big, totals + 2, lenhist, gshift);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist, gshift);
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
@@ -1169,9 +1169,8 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2);
+                       split_small, split_big, totals + 2, lenhist, gshift);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_hist, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenhist, gshift);
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
