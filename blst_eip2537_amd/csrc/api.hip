@@ -964,6 +964,61 @@ API int eip2537_hip_set_window(int c) {
     return 0;
 }
 
+// Device self-test of the field products: n pseudo-random operand pairs (every eighth pair from a table
+// of extreme values) through the column products the kernels use -- canonical and lazy, product and
+// square -- against the independent 12 x 32-bit CIOS product, all on the device. Guards the products
+// against code generation differences between host and device (field.h, radix 2^30 note).
+__device__ static Fp selftest_operand(uint64_t &s, unsigned idx) {
+    Fp v;
+    for (int k = 0; k < 12; k += 2) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        v.l[k] = (uint32_t)s;
+        v.l[k + 1] = (uint32_t)(s >> 32);
+    }
+    if ((idx & 7) == 7) {
+        const unsigned kind = (idx >> 3) % 6;
+        const uint32_t p[12] = {K_P};
+        for (int k = 0; k < 12; k++)
+            v.l[k] = kind == 0 ? 0u : kind == 1 ? 0xffffffffu : kind == 2 ? p[k] : kind == 3 ? (k == 0 ? 1u : 0u)
+                   : kind == 4 ? (k & 1 ? 0xffffffffu : 0u) : (v.l[k] | 0x3fffffffu);
+        if (kind == 2) v.l[0] -= 1 + ((idx >> 6) & 1);          // p - 1, p - 2
+    }
+    v.l[11] &= 0x0fffffffu;                                     // below 2^380 < 2p: legal for every product
+    return v;
+}
+__global__ void k_field_selftest(uint64_t seed, unsigned n, unsigned long long *bad) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = (seed ^ (0x9E3779B97F4A7C15ull * (i + 1))) | 1;
+    const Fp a = selftest_operand(s, i), b = selftest_operand(s, i + 3);
+    const Fp want = fp_mul_limbs32(a, b), want2 = fp_mul_limbs32(a, a);
+    if (!eq(fp_mul_cols_t<true>(a, b), want)) atomicAdd(&bad[0], 1ull);
+    if (!eq(fp_sqr_cols_t<true>(a), want2)) atomicAdd(&bad[1], 1ull);
+    if (!eq(fp_canon(mul(FpI{a}, FpI{b})), want)) atomicAdd(&bad[2], 1ull);
+    if (!eq(fp_canon(sqr(FpI{a})), want2)) atomicAdd(&bad[3], 1ull);
+}
+API int eip2537_hip_field_selftest(uint64_t seed, size_t n, uint64_t mismatches[4]) {
+    if (!mismatches || n == 0 || n > (1u << 24)) return E_INVALID_LENGTH;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!device_select_locked()) return E_MEMORY_ERROR;
+    }
+    DeviceGuard guard(g_pools[g_split[0]].ordinal);
+    if (!guard.ok) return E_MEMORY_ERROR;
+    unsigned long long *d_bad = nullptr;
+    if (hipMalloc(&d_bad, 4 * sizeof(unsigned long long)) != hipSuccess) return E_MEMORY_ERROR;
+    unsigned long long h_bad[4] = {0, 0, 0, 0};
+    bool ok = hipMemset(d_bad, 0, sizeof(h_bad)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_field_selftest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, seed, (unsigned)n, d_bad);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_bad);
+    if (!ok) return E_MEMORY_ERROR;
+    for (int k = 0; k < 4; k++) mismatches[k] = h_bad[k];
+    return 0;
+}
+
 // Synthetic workloads of SURVEY.md 8d (host code; used by bench.py and the tests, never by a precompile)
 API int eip2537_hip_gen_g1_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t seed, uint64_t start) {
     return gen_msm_input<Fp>(out, n, a_le, b_le, seed, start, 160, true);

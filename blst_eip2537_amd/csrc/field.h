@@ -158,6 +158,133 @@ HD Fp fp_mul_limbs32(const Fp &a, const Fp &b) {
     return fp_reduce_once(r);
 }
 
+// ---- radix 2^30 (13 limbs) ------------------------------------------------------------------------------
+// 13 x 13 + 13 x 13 = 338 multiply-adds instead of the 392 of the 14 x 28-bit form below.  A column of
+// 26 products of 30-bit limbs would overflow its 64-bit accumulator by 0.7 bit, so the columns that can
+// collect more than 16 terms (8 .. 16) are carried out ONCE, after outer step 7, when each of them holds at
+// most 16 terms (16 (2^30 - 1)^2 + 2^34 < 2^64); the five remaining steps add at most 10 more.  The
+// reduction clears 12 x 30 + 24 = 384 bits, so R = 2^384 and the results are bit-identical to every other
+// product in this file.  Inputs may be in [0, 2p) (FpI); REDUCE = false leaves the result below 1.41 p.
+// hipcc (ROCm 7.2, gfx950) miscompiles the 13-limb product when it can see that the last reduction
+// factor is "x & 0xffffff": the 24-bit multiply combine drops the mask (its instruction ignores bits
+// 24..31), and the sum of the two 24 x 24-bit products of column 24 is then selected as v_mad_u64_u32
+// on the UNMASKED register (tools/dev_mul_check.hip: 99.6 % wrong products on the device, none on the
+// host). The 14 x 28-bit product masks its last factor to 20 bits and is not affected. The empty asm
+// hides a value's range from the optimiser and emits no instruction; it is applied to the reduction
+// factors and to the limbs.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EIP_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define EIP_OPAQUE(x)
+#endif
+template <bool REDUCE> HD Fp fp_mul_cols30_t(const Fp &a, const Fp &b) {
+    const uint32_t p30[13] = {K_P30};
+    const uint32_t M30 = 0x3fffffffu;
+    uint32_t al[13], bl[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int bit = 30 * k, i = bit >> 5, s = bit & 31;
+        uint32_t va = a.l[i] >> s, vb = b.l[i] >> s;
+        if (s > 2 && i + 1 < 12) { va |= a.l[i + 1] << (32 - s); vb |= b.l[i + 1] << (32 - s); }
+        al[k] = va & M30;
+        bl[k] = vb & M30;
+        EIP_OPAQUE(al[k]);
+        EIP_OPAQUE(bl[k]);
+    }
+    uint64_t col[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) col[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)al[j] * bl[i];
+        // last step clears only 24 bits: 12 * 30 + 24 = 384
+        uint32_t m = ((uint32_t)col[i] * K_N0_30) & (i < 12 ? M30 : 0x00ffffffu);
+        EIP_OPAQUE(m);
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)m * p30[j];
+        if (i < 12) col[i + 1] += col[i] >> 30;
+        if (i == 7) {
+#pragma unroll
+            for (int c = 8; c <= 16; c++) { col[c + 1] += col[c] >> 30; col[c] &= (uint64_t)M30; }
+        }
+    }
+    // digits 12..25 hold (result << 24); propagate carries, then cut 32-bit words at bit 24
+    uint32_t d[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        uint64_t v = col[12 + k] + carry;
+        d[k] = (uint32_t)v & M30;
+        carry = v >> 30;
+    }
+    d[14] = 0;
+    d[15] = 0;
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 24 + 32 * w, q = bit / 30, o = bit % 30;
+        uint64_t t = (uint64_t)d[q] | ((uint64_t)d[q + 1] << 30) | ((uint64_t)d[q + 2] << 60);
+        r.l[w] = (uint32_t)(t >> o);
+    }
+    return REDUCE ? fp_reduce_once(r) : r;
+}
+// Squaring: the 78 cross products are computed once against a doubled operand (91 + 169 multiply-adds);
+// the product phase leaves at most 13 terms per column, columns 8 .. 16 are carried out before the
+// reduction adds up to 13 more.
+template <bool REDUCE> HD Fp fp_sqr_cols30_t(const Fp &a) {
+    const uint32_t p30[13] = {K_P30};
+    const uint32_t M30 = 0x3fffffffu;
+    uint32_t al[13], a2[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int bit = 30 * k, i = bit >> 5, s = bit & 31;
+        uint32_t va = a.l[i] >> s;
+        if (s > 2 && i + 1 < 12) va |= a.l[i + 1] << (32 - s);
+        al[k] = va & M30;
+        EIP_OPAQUE(al[k]);
+        a2[k] = al[k] << 1;
+        EIP_OPAQUE(a2[k]);
+    }
+    uint64_t col[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) col[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        col[2 * i] += (uint64_t)al[i] * al[i];
+#pragma unroll
+        for (int j = i + 1; j < 13; j++) col[i + j] += (uint64_t)a2[j] * al[i];
+    }
+#pragma unroll
+    for (int c = 8; c <= 16; c++) { col[c + 1] += col[c] >> 30; col[c] &= (uint64_t)M30; }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        uint32_t m = ((uint32_t)col[i] * K_N0_30) & (i < 12 ? M30 : 0x00ffffffu);
+        EIP_OPAQUE(m);
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)m * p30[j];
+        if (i < 12) col[i + 1] += col[i] >> 30;
+    }
+    uint32_t d[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        uint64_t v = col[12 + k] + carry;
+        d[k] = (uint32_t)v & M30;
+        carry = v >> 30;
+    }
+    d[14] = 0;
+    d[15] = 0;
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 24 + 32 * w, q = bit / 30, o = bit % 30;
+        uint64_t t = (uint64_t)d[q] | ((uint64_t)d[q + 1] << 30) | ((uint64_t)d[q + 2] << 60);
+        r.l[w] = (uint32_t)(t >> o);
+    }
+    return REDUCE ? fp_reduce_once(r) : r;
+}
+
 // Device Montgomery product.  The operands arrive as canonical 12 x 32-bit limbs and are
 // re-sliced into 14 x 28-bit limbs so that every multiply-add of the schoolbook product and of
 // the reduction is ONE v_mad_u64_u32 accumulating in place into a 64-bit column: 28 terms of
@@ -261,6 +388,30 @@ template <bool REDUCE> HD Fp fp_sqr_cols28_t(const Fp &a) {
 }
 HD Fp fp_sqr_cols28(const Fp &a) { return fp_sqr_cols28_t<true>(a); }
 
+// The product the device kernels use: radix 2^30 (13 limbs, 338 multiply-adds) by default, measured
+// 3 % faster end to end than radix 2^28 (14 limbs, 392) on all three workloads;
+// -DEIP_LIMB_BITS=28 builds the library on the 28-bit form.
+#ifndef EIP_LIMB_BITS
+#define EIP_LIMB_BITS 30
+#endif
+template <bool REDUCE> HD Fp fp_mul_cols_t(const Fp &a, const Fp &b) {
+#if EIP_LIMB_BITS == 30
+    return fp_mul_cols30_t<REDUCE>(a, b);
+#else
+    return fp_mul_cols28_t<REDUCE>(a, b);
+#endif
+}
+template <bool REDUCE> HD Fp fp_sqr_cols_t(const Fp &a) {
+#if EIP_LIMB_BITS == 30
+    return fp_sqr_cols30_t<REDUCE>(a);
+#else
+    return fp_sqr_cols28_t<REDUCE>(a);
+#endif
+}
+// Canonical results in [0, p).
+HD Fp fp_mul_cols(const Fp &a, const Fp &b) { return fp_mul_cols_t<true>(a, b); }
+HD Fp fp_sqr_cols(const Fp &a) { return fp_sqr_cols_t<true>(a); }
+
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host: the same 48 bytes as 6 x 64-bit limbs.  Operand scanning with whole rows of 64x64->128
@@ -348,8 +499,8 @@ inline Fp fp_mul_adx(const Fp &a, const Fp &b) {
 static __device__ __noinline__ Fp fp_mul_outlined(Fp a, Fp b) { return fp_mul_limbs32(a, b); }
 static __device__ __noinline__ Fp fp_sqr_outlined(Fp a) { return fp_mul_limbs32(a, a); }
 #else
-static __device__ __noinline__ Fp fp_mul_outlined(Fp a, Fp b) { return fp_mul_cols28(a, b); }
-static __device__ __noinline__ Fp fp_sqr_outlined(Fp a) { return fp_sqr_cols28(a); }
+static __device__ __noinline__ Fp fp_mul_outlined(Fp a, Fp b) { return fp_mul_cols(a, b); }
+static __device__ __noinline__ Fp fp_sqr_outlined(Fp a) { return fp_sqr_cols(a); }
 #endif
 #endif
 
@@ -410,7 +561,7 @@ HD Fp2 conj(const Fp2 &a) { return Fp2{a.c0, neg(a.c1)}; }
 // spill traffic), the 64-bit host product otherwise.
 HD Fp fp_mul_leaf(const Fp &a, const Fp &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return fp_mul_cols28(a, b);
+    return fp_mul_cols(a, b);
 #else
     return fp_mul_host(a, b);
 #endif
@@ -426,7 +577,7 @@ HD Fp2 fp2_sqr_body(const Fp2 &a) {
     return Fp2{fp_mul_leaf(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
 }
 // On the device the Fp2 product and square are out of line as well.  Besides keeping the code
-// objects small this is a correctness guard: with fp_mul_cols28 and everything above it inlined,
+// objects small this is a correctness guard: with fp_mul_cols and everything above it inlined,
 // hipcc 7.2 -O3 miscompiled k_pair_check_g2 (256 VGPR + 256 AGPR + scratch spills; the same
 // source was correct at -O1, with the 32-bit CIOS product, and in a smaller kernel) -- found by
 // the GPU parity tests, isolated by compiling that kernel alone at -O1 / -O3 and with either product.
@@ -527,8 +678,8 @@ HD FpI sub(const FpI &a, const FpI &b) {
     for (int i = 0; i < 12; i++) r.v.l[i] = borrow ? e.l[i] : d.l[i];
     return r;
 }
-HD FpI mul(const FpI &a, const FpI &b) { return FpI{fp_mul_cols28_t<false>(a.v, b.v)}; }
-HD FpI sqr(const FpI &a) { return FpI{fp_sqr_cols28_t<false>(a.v)}; }
+HD FpI mul(const FpI &a, const FpI &b) { return FpI{fp_mul_cols_t<false>(a.v, b.v)}; }
+HD FpI sqr(const FpI &a) { return FpI{fp_sqr_cols_t<false>(a.v)}; }
 #else       // the host pass only parses the kernels that use FpI
 HD bool is_zero(const FpI &a) { return is_zero(a.v); }
 HD FpI add(const FpI &a, const FpI &b) { return FpI{add(a.v, b.v)}; }

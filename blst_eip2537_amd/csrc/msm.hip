@@ -364,7 +364,7 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
 template <int HOT, class T> __device__ __forceinline__ T hmul(const T &a, const T &b) { return mul(a, b); }
 #if defined(__HIP_DEVICE_COMPILE__)
 template <> __device__ __forceinline__ Fp2 hmul<1, Fp2>(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
-template <> __device__ __forceinline__ Fp hmul<2, Fp>(const Fp &a, const Fp &b) { return fp_mul_cols28(a, b); }
+template <> __device__ __forceinline__ Fp hmul<2, Fp>(const Fp &a, const Fp &b) { return fp_mul_cols(a, b); }
 template <> __device__ __forceinline__ Fp2 hmul<2, Fp2>(const Fp2 &a, const Fp2 &b) { return fp2_mul_body(a, b); }
 #endif
 

@@ -384,7 +384,7 @@ __device__ __forceinline__ void scale_line(LineRec &l, const Aff<Fp> &P, int sub
     const int r = sub & 3;
     const Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const Fp q = fp_mul_cols28(w, r < 2 ? P.x : P.y);
+    const Fp q = fp_mul_cols(w, r < 2 ? P.x : P.y);
 #else
     const Fp q = mul(w, r < 2 ? P.x : P.y);
 #endif

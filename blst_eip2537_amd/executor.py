@@ -94,6 +94,8 @@ def lib():
     L.eip2537_hip_set_route.argtypes = [ctypes.c_int]
     L.eip2537_hip_set_window.restype = ctypes.c_int
     L.eip2537_hip_set_window.argtypes = [ctypes.c_int]
+    L.eip2537_hip_field_selftest.restype = ctypes.c_int
+    L.eip2537_hip_field_selftest.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
     L.eip2537_hip_device_count.restype = ctypes.c_int
     L.eip2537_hip_device_count.argtypes = []
     L.eip2537_hip_trim.restype = ctypes.c_size_t
@@ -245,6 +247,16 @@ class Eip2537Executor:
         rc = lib().eip2537_hip_set_route(route)
         if rc != 0:
             raise Eip2537Error(rc)
+
+    @staticmethod
+    def field_selftest(seed, n):
+        """Mismatch counts (product, square, lazy product, lazy square) of the device Fp products on n
+        operand pairs against the independent 12 x 32-bit product (eip2537_hip.h)."""
+        bad = (ctypes.c_uint64 * 4)()
+        rc = lib().eip2537_hip_field_selftest(seed, n, bad)
+        if rc != 0:
+            raise Eip2537Error(rc)
+        return tuple(bad)
 
     @staticmethod
     def set_window(c):

@@ -94,6 +94,11 @@ int eip2537_hip_set_route(int route);
 /* Testing hook: force the Pippenger window width (4..16); 0 restores the cost model. */
 int eip2537_hip_set_window(int c);
 
+/* Device self-test of the Fp products (column product and square, canonical and lazy forms) on n
+ * pseudo-random and extreme operand pairs against an independent 12 x 32-bit product, all on the device.
+ * mismatches[0..3] = product, square, lazy product, lazy square.  Returns 0 when the test ran. */
+int eip2537_hip_field_selftest(uint64_t seed, size_t n, uint64_t mismatches[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,11 @@ def test_pairing_small_order_g1_points(X, clib):
     assert call_x(X.pairing, n3 + g2) == clib.call("bls12_pairing", n3 + g2) == (2, None)
     inp = bytes(128) + g2 + p3 + g2
     assert call_x(X.pairing, inp) == clib.call("bls12_pairing", inp) == (2, None)
+
+
+def test_device_field_products_selftest(X):
+    """The column products the kernels use (radix 2^30; canonical and lazy, product and square) against
+    the independent 12 x 32-bit product, on the device: guards against the code-generation problem
+    recorded in field.h (the host build of the same source was correct, the device build was not)."""
+    for seed in (1, 0x2537):
+        assert X.field_selftest(seed, 1 << 18) == (0, 0, 0, 0)

@@ -56,6 +56,21 @@ template <int V> __global__ void __launch_bounds__(256) chain(uint32_t *out, int
         x.l[0] ^= (threadIdx.x + salt) & 0xff;
         for (int i = 0; i < iters; i++) x = fp_sqr_cols28(x);
         for (int i = 0; i < 12; i++) acc ^= x.l[i];
+    } else if (V == 4) {
+        Fp x{A32}, y{B32};
+        x.l[0] ^= (threadIdx.x + salt) & 0xff;
+        for (int i = 0; i < iters; i++) x = fp_mul_cols30_t<true>(x, y);
+        for (int i = 0; i < 12; i++) acc ^= x.l[i];
+    } else if (V == 5) {
+        Fp x{A32};
+        x.l[0] ^= (threadIdx.x + salt) & 0xff;
+        for (int i = 0; i < iters; i++) x = fp_sqr_cols30_t<true>(x);
+        for (int i = 0; i < 12; i++) acc ^= x.l[i];
+    } else if (V == 6) {
+        FpI x{Fp{A32}}, y{Fp{B32}};
+        x.v.l[0] ^= (threadIdx.x + salt) & 0xff;
+        for (int i = 0; i < iters; i++) x = mul(x, y);
+        for (int i = 0; i < 12; i++) acc ^= x.v.l[i];
     } else {
         Fq x{A28}, y{B28};
         x.l[0] ^= (threadIdx.x + salt) & 0xff;
@@ -101,5 +116,8 @@ int main() {
     run<1>("V1 14x28 column accumulators", d);
     run<2>("V2 V1 as drop-in (12x32 in/out)", d);
     run<3>("V3 squaring, drop-in", d);
+    run<4>("V4 13x30 columns, drop-in", d);
+    run<5>("V5 13x30 squaring, drop-in", d);
+    run<6>("V6 lazy product (library default)", d);
     return 0;
 }
