@@ -45,7 +45,7 @@ B = 0x0123456789abcdef0fedcba987654321
 R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MAD_PEAK = 29441.6e9           # v_mad_u64_u32 lane-ops/s, chip-wide, measured (profiles/r01_valu_probe.txt)
-MADS_PER_FP_PRODUCT = 392      # 14 x 14 product + 14 x 14 reduction columns of 28-bit limbs (csrc/field.h)
+MADS_PER_FP_PRODUCT = 338      # 13 x 13 product + 13 x 13 reduction columns of 30-bit limbs (csrc/field.h)
 REC = {"g1msm": 160, "g2msm": 288, "pairing": 384}          # algorithmic bytes per unit
 FULL = {"g1msm": "eip2537_hip_g1multiexp_dev", "g2msm": "eip2537_hip_g2multiexp_dev",
         "pairing": "eip2537_hip_pairing_dev"}
