@@ -23,6 +23,7 @@
 #include <vector>
 #include "codec.h"
 #include "lanes.h"
+#include "limb30.h"
 #include "engine.h"
 
 namespace eip {
@@ -116,9 +117,35 @@ __device__ __forceinline__ void for_each_digit(const uint32_t k[8], const MsmPla
 }
 
 
+// Point record of the limb-form accumulate (limb30.h): x R', y R' and -y R' in 13 limbs each (the sign
+// of a window digit then only picks an address), 14 dwords apart so that every coordinate is 8-byte aligned.
+struct PtL { uint32_t x[14], y[14], ny[14]; };
+__device__ __forceinline__ void store_limbs(uint32_t *dst, const FpL &v) {
+#pragma unroll
+    for (int k = 0; k < 14; k += 2)
+        *reinterpret_cast<uint2 *>(dst + k) = make_uint2(v.l[k], k + 1 < 13 ? v.l[k + 1] : 0u);
+}
+__device__ __forceinline__ FpL load_limbs(const uint32_t *src) {
+    FpL v;
+#pragma unroll
+    for (int k = 0; k < 14; k += 2) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(src + k);
+        v.l[k] = t.x;
+        if (k + 1 < 13) v.l[k + 1] = t.y;
+    }
+    return v;
+}
+__device__ __forceinline__ void store_point_limbs(PtL *dst, const Aff<Fp> &a) {
+    const Fp yr = mul(a.y, Fp{{K_R390_MODP}});
+    store_limbs(dst->x, fpl_from_mont(a.x));
+    store_limbs(dst->y, to_limbs(yr));
+    store_limbs(dst->ny, to_limbs(neg(yr)));
+}
+__device__ __forceinline__ void store_point_limbs(PtL *, const Aff<Fp2> &) {}
+
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts,
+k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts, PtL *__restrict__ ptl,
              uint32_t *__restrict__ digits, unsigned long long *err) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool live = false;
@@ -130,7 +157,8 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
         if (st != E_SUCCESS) {
             atomicMin(err, ((unsigned long long)i << 3) | (unsigned long long)st);
         } else if (!is_inf(a)) {
-            pts[i] = a;
+            if (ptl) store_point_limbs(&ptl[i], a);
+            else pts[i] = a;
             live = true;
             decode_scalar(k, w + Wire<F>::kPointWords);
         }
@@ -525,6 +553,28 @@ k_msm_accum(const Aff<F> *__restrict__ pts_, const uint32_t *__restrict__ entrie
     partial[t] = acc;
 }
 
+// ---- limb-form accumulate (one lane per task, G1, the throughput-bound plans) ------------------------
+// The same mixed addition as madd() on FpL values (limb30.h): no re-slicing between products, no
+// conditional corrections.  Bounds held by the accumulator between entries (in units of p):
+//   x < 8, y < 4, zz < 2, zzz < 2;   inside: P < 10, R < 6, every product of a b < 630.
+__global__ void __launch_bounds__(256)
+k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
+              const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp> *__restrict__ partial_) {
+    Xyzz<FpI> *__restrict__ partial = reinterpret_cast<Xyzz<FpI> *>(partial_);
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= totals[1]) return;
+    const uint32_t t = perm[slot];
+    const Task tk = tasks[t];
+    AccL acc;
+    bool inf = true;
+    for (uint32_t e = 0; e < tk.len; e++) {
+        const uint32_t ent = entries[tk.start + e];
+        const PtL *q = &pts[ent >> 1];
+        madd_l(acc, inf, load_limbs(q->x), load_limbs((ent & 1u) ? q->ny : q->y));
+    }
+    partial[t] = inf ? xyzz_inf<FpI>() : Xyzz<FpI>{to_fpi(acc.x), to_fpi(acc.y), to_fpi(acc.zz), to_fpi(acc.zzz)};
+}
+
 // ---- fold: buckets that were split into several tasks ------------------------------------------
 // A bucket with more than L entries (the top window when it has only a few bits, duplicate-heavy
 // or adversarial inputs: all scalars equal puts every record of a window into ONE bucket) leaves
@@ -817,14 +867,16 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     }
 }
 
-static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const uint32_t *entries,
+static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const PtL *ptl, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
     if (chain_bound)
         hipLaunchKernelGGL(k_msm_accum2<Fp>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    else if (ptl)
+        hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial);
     else
         hipLaunchKernelGGL(k_msm_accum<Fp>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
-static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp2> *pts, const uint32_t *entries,
+static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp2> *pts, const PtL *, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
     hipLaunchKernelGGL(k_msm_accum2c, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
@@ -903,7 +955,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     const size_t nwin_out = red_blocks;
 
-    HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
+    // G1 plans that take the one-lane accumulate run it in limb form (limb30.h): the decode kernel
+    // writes 168-byte limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernel.
+    static const bool env_limb = [] { const char *v = getenv("EIP2537_LIMB_FORM"); return !v || atoi(v) != 0; }();
+    const bool limb_form = !ReduceCfg<F>::kFourLane && pl.c > 13 && env_limb;
+    HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
     const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
@@ -948,12 +1004,14 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
         LastPlan lp{};
         if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");        // G2: split by component
+        else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum_l");
         else snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
         lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB;
         e->last_plan = lp;
     }
     HIPCHK(hipEventRecord(e->ev_start, s));
-    hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, digits, err);
+    PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
+    hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, ptl, digits, err);
     hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
@@ -973,7 +1031,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
     // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
-    launch_accum(s, task_blocks, pl.c <= 13, pts, entries, tasks, perm, totals, partial);
+    launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
     launch_fold_small(s, four, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
@@ -1174,7 +1232,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    launch_accum(s, task_blocks, true, pts, entries, tasks, perm, totals, partial);      // two lanes per task
+    launch_accum(s, task_blocks, true, pts, nullptr, entries, tasks, perm, totals, partial);      // two lanes per task
     HIPCHK(hipEventRecord(e->ev_b, s));
     launch_fold_small(s, true, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);

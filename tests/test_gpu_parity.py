@@ -60,6 +60,15 @@ def test_g1_msm_adversarial(X, clib):
         assert call_x(X.g1_multiexp, inp) == clib.call("bls12_g1multiexp", inp), name
         assert call_x(X.g1_multiexp_bc, inp) == clib.call("bls12_g1multiexp_bc", inp), name
         assert call_x(X.g1_multiexp_naive, inp) == clib.call("bls12_g1multiexp_naive", inp), name
+    # the same inputs through the plan of the large sizes (c = 16: one lane per task, limb-form accumulate,
+    # csrc/limb30.h) -- equal, opposite and repeated entries meet its doubling and cancellation paths
+    X.set_window(16)
+    try:
+        for name, inp in cases.items():
+            assert call_x(X.g1_multiexp, inp) == clib.call("bls12_g1multiexp", inp), name + " (c = 16)"
+        assert X.last_plan()["kernel"] == "k_msm_accum_l"
+    finally:
+        X.set_window(0)
 
 
 def test_g2_msm_adversarial(X, clib):

@@ -1,0 +1,21 @@
+"""Host run of the limb-form arithmetic behind k_msm_accum_l (csrc/limb30.h): the same HD source compiled
+for the host by tools/limb30_check.hip, checked against the 64-bit host product and the generic madd()."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_limb_form_matches_host_arithmetic(tmp_path):
+    exe = str(tmp_path / "limb30_check")
+    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "--offload-arch=gfx950", "-Xarch_host", "-mbmi2", "-Xarch_host", "-madx",
+                           "-I" + os.path.join(ROOT, "blst_eip2537_amd", "csrc"), os.path.join(ROOT, "tools", "limb30_check.hip"),
+                           "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout
+    assert "field operations: 0 mismatches" in out.stdout and "accumulate chains: 0 mismatches" in out.stdout
