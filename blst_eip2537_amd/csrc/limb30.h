@@ -192,6 +192,54 @@ HD FpL sqrL(const FpL &a) {
     return fpl_take_high(col);
 }
 
+// (a b + c d) / 2^390 + (< p) with ONE reduction, for a b + c d < 630 p^2: 169 multiply-adds and a carry
+// pass less than two products and an addition.  Columns 8 .. 16 are carried out after the first 169
+// products (13 terms each), columns 4 .. 20 after the second (the reduction adds up to 13 more terms;
+// the columns outside hold at most 8 product terms).
+HD FpL mul2L(const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
+    const uint32_t p30[13] = {K_P30};
+    uint64_t col[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) col[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)a.l[j] * b.l[i];
+    }
+#pragma unroll
+    for (int k = 8; k <= 16; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)kM30; }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)c.l[j] * d.l[i];
+    }
+#pragma unroll
+    for (int k = 4; k <= 20; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)kM30; }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const uint32_t m = ((uint32_t)col[i] * K_N0_30) & kM30;
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)m * p30[j];
+        col[i + 1] += col[i] >> 30;
+    }
+    return fpl_take_high(col);
+}
+// K p - b, for b <= K p
+template <int K> HD FpL negL(const FpL &b) {
+    uint32_t kp[13];
+    kp30<K>(kp);
+    FpL r;
+    int32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int32_t t = (int32_t)(kp[k] - b.l[k]) + c;
+        r.l[k] = (uint32_t)t & kM30;
+        c = t >> 30;
+    }
+    r.l[12] = kp[12] - b.l[12] + (uint32_t)c;
+    return r;
+}
+
 // x R (12 x 32, canonical, Montgomery factor R = 2^384) -> x R' in limbs, through one product of the R world
 HD FpL fpl_from_mont(const Fp &a) { return to_limbs(mul(a, Fp{{K_R390_MODP}})); }
 // x R' (< 600 p) -> x R in [0, 2p) as 12 x 32-bit words
@@ -226,10 +274,9 @@ HD void madd_l(AccL &acc, bool &inf, const FpL &qx, const FpL &qy) {
     }
     const FpL PP = sqrL(P), PPP = mulL(P, PP), Q = mulL(acc.x, PP);
     const FpL X3 = sub2L<4>(subL<2>(sqrL(R), PPP), Q);            // R^2 - PPP - 2Q + 6p < 8
-    const FpL t1 = mulL(acc.y, PPP);
     acc.zz = mulL(acc.zz, PP);
     acc.zzz = mulL(acc.zzz, PPP);
-    acc.y = subL<2>(mulL(R, subL<8>(Q, X3)), t1);                 // Q - X3 + 8p < 10; result < 4
+    acc.y = mul2L(R, subL<8>(Q, X3), acc.y, negL<2>(PPP));        // R (Q - X3) - Y1 PPP: 6 x 10 + 4 x 2 < 630; result < 2
     acc.x = X3;
 }
 

@@ -33,6 +33,7 @@ int main() {
         const FpL g1 = subL<8>(A, B), g2 = subL<6>(B, A);
         if (!eq(canon_of(mulL(g1, g2)), mul(sub(a, b), sub(b, a)))) bad++;
         if (!eq(canon_of(sqrL(g1)), sqr(sub(a, b)))) bad++;
+        if (!eq(canon_of(mul2L(g1, g2, A, negL<2>(B))), sub(mul(sub(a, b), sub(b, a)), mul(a, b)))) bad++;
         if (is_zero_modp(g1, 10) != eq(a, b)) bad++;
         if (!is_zero_modp(subL<8>(A, A), 10) || !is_zero_modp(subL<3>(A, A), 4)) bad++;
     }
