@@ -280,4 +280,46 @@ HD void madd_l(AccL &acc, bool &inf, const FpL &qx, const FpL &qy) {
     acc.x = X3;
 }
 
+// ---- complete XYZZ operations on limb-form points (fold and one-lane reduce kernels) ----------------
+// "Standard" bounds of a stored point, in units of p: x < 8, y < 4, zz < 2, zzz < 2 (what madd_l, add and
+// dbl below all produce).  The point at infinity is zz = 0 in all limbs: a computed zz is a product of
+// values that are not multiples of p and is never 0 mod p, and 0 * anything stays exactly 0 in mulL.
+template <> HD FpL f_zero<FpL>() { return fpl_zero(); }
+template <> HD FpL f_one<FpL>() { return fpl_one(); }
+HD bool is_zero(const FpL &a) {                       // exact zero only (the infinity marker)
+    uint32_t z = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) z |= a.l[k];
+    return z == 0;
+}
+// 2P (dbl-2008-s-1); infinity stays infinity because ZZ3 = V * ZZ
+HD Xyzz<FpL> dbl(const Xyzz<FpL> &p) {
+    const FpL U = addL(p.y, p.y);                                 // < 8
+    const FpL V = sqrL(U), W = mulL(U, V), S = mulL(p.x, V), XX = sqrL(p.x);     // 64, 16, 16, 64 < 630
+    const FpL M = dbl_addL(XX, XX);                               // < 6
+    const FpL X3 = sub2L<4>(sqrL(M), S);                          // < 6
+    const FpL Y3 = mul2L(M, subL<6>(S, X3), W, negL<4>(p.y));     // M (S - X3) - W Y1: 6 x 8 + 2 x 4; < 2
+    return Xyzz<FpL>{X3, Y3, mulL(V, p.zz), mulL(W, p.zzz)};
+}
+// P + Q (add-2008-s), complete
+HD Xyzz<FpL> add(const Xyzz<FpL> &p, const Xyzz<FpL> &q) {
+    if (is_zero(q.zz)) return p;
+    if (is_zero(p.zz)) return q;
+    const FpL U1 = mulL(p.x, q.zz), U2 = mulL(q.x, p.zz), S1 = mulL(p.y, q.zzz), S2 = mulL(q.y, p.zzz);   // 16, 16, 8, 8
+    const FpL P = subL<2>(U2, U1), R = subL<2>(S2, S1);           // < 4
+    if (is_zero_modp(P, 4)) {
+        if (is_zero_modp(R, 4)) return dbl(p);
+        return Xyzz<FpL>{fpl_zero(), fpl_zero(), fpl_zero(), fpl_zero()};
+    }
+    const FpL PP = sqrL(P), PPP = mulL(P, PP), Q = mulL(U1, PP);
+    const FpL X3 = sub2L<4>(subL<2>(sqrL(R), PPP), Q);            // < 8
+    const FpL Y3 = mul2L(R, subL<8>(Q, X3), S1, negL<2>(PPP));    // R (Q - X3) - S1 PPP: 4 x 10 + 2 x 2; < 2
+    return Xyzz<FpL>{X3, Y3, mulL(mulL(p.zz, q.zz), PP), mulL(mulL(p.zzz, q.zzz), PPP)};
+}
+// back to the canonical 12 x 32-bit form of every other kernel and of the host
+HD Xyzz<Fp> canon(const Xyzz<FpL> &p) {
+    return Xyzz<Fp>{fp_reduce_once(to_fpi(p.x).v), fp_reduce_once(to_fpi(p.y).v), fp_reduce_once(to_fpi(p.zz).v),
+                    fp_reduce_once(to_fpi(p.zzz).v)};
+}
+
 }  // namespace eip

@@ -560,7 +560,7 @@ k_msm_accum(const Aff<F> *__restrict__ pts_, const uint32_t *__restrict__ entrie
 __global__ void __launch_bounds__(256)
 k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
               const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp> *__restrict__ partial_) {
-    Xyzz<FpI> *__restrict__ partial = reinterpret_cast<Xyzz<FpI> *>(partial_);
+    Xyzz<FpL> *__restrict__ partial = reinterpret_cast<Xyzz<FpL> *>(partial_);     // read by the <Fp, FpL> fold and reduce kernels
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= totals[1]) return;
     const uint32_t t = perm[slot];
@@ -572,7 +572,7 @@ k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries,
         const PtL *q = &pts[ent >> 1];
         madd_l(acc, inf, load_limbs(q->x), load_limbs((ent & 1u) ? q->ny : q->y));
     }
-    partial[t] = inf ? xyzz_inf<FpI>() : Xyzz<FpI>{to_fpi(acc.x), to_fpi(acc.y), to_fpi(acc.zz), to_fpi(acc.zzz)};
+    partial[t] = inf ? xyzz_inf<FpL>() : Xyzz<FpL>{acc.x, acc.y, acc.zz, acc.zzz};
 }
 
 // ---- fold: buckets that were split into several tasks ------------------------------------------
@@ -582,15 +582,23 @@ k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries,
 // reduce kernels read.  (Summing them serially inside the reduce cost 93 ms at n = 2^18, where the
 // top window has 1 bit and its two buckets ~2000 tasks each; a block per split bucket cost 30 ms
 // when most buckets had 2-4 tasks -- hence two tiers, and L grows with the mean bucket load.)
+__device__ __forceinline__ FpL shfl_from(const FpL &a, int src) {
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = __shfl(a.l[i], src, 64);
+    return r;
+}
+// per-block window sums leave the device in the canonical form the host reads, whatever the kernel computed in
+template <class F, class T> __device__ __forceinline__ void store_canon(Xyzz<F> *out, const Xyzz<T> &v) { *reinterpret_cast<Xyzz<T> *>(out) = canon(v); }
+template <> __device__ __forceinline__ void store_canon<Fp, FpL>(Xyzz<Fp> *out, const Xyzz<FpL> &v) { *out = canon(v); }
 // out-of-line complete point operations (fold and one-lane reduce kernels)
 template <class T> static __device__ __noinline__ void xyzz_add_o(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
 template <class T> static __device__ __noinline__ void xyzz_dbl_o(Xyzz<T> *r, const Xyzz<T> *a) { *r = dbl(*a); }
 // 2..8 tasks: one thread per bucket
-template <class F>
+template <class F, class T = typename AccumField<F>::T>    // T: the form the accumulate kernel wrote the partials in (G1: FpI or FpL)
 __global__ void __launch_bounds__(256)
 k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                  const uint32_t *__restrict__ split_counts) {
-    using T = typename AccumField<F>::T;              // G1: FpI, like the kernel that wrote the partials
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
     for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < n; h += gridDim.x * 256u) {
@@ -604,11 +612,10 @@ k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ ta
     }
 }
 // more than 8 tasks: one block per bucket -- 256 strided serial chains, shuffle tree, LDS step
-template <class F>
+template <class F, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256)
 k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                const uint32_t *__restrict__ split_counts) {
-    using T = typename AccumField<F>::T;              // G1: FpI, like the kernel that wrote the partials
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     __shared__ Xyzz<T> sm[4];
     const uint32_t nh = split_counts[1];
@@ -818,13 +825,11 @@ k_msm_reduce8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict
 // Measured at 2^20 / c = 16: 1.55 ms against 1.8-2.1 ms for the 4-lane form above (whose per-round
 // select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
 // products are 3x heavier and the 4-lane form wins 2.2 ms to 7.0 ms at 2^16.
-template <class F>
+template <class F, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256)
 k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
-              Xyzz<F> *__restrict__ winout_) {
-    using T = typename AccumField<F>::T;
+              Xyzz<F> *__restrict__ winout) {
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
-    Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
     int w;
     uint32_t bx;
     reduce_block_to_window(rg, pl, w, bx);
@@ -863,7 +868,7 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; k++) xyzz_add_o<T>(&C, &C, &sm[k]);
-        winout[blockIdx.x] = canon(C);
+        store_canon<F, T>(&winout[blockIdx.x], C);
     }
 }
 
@@ -880,21 +885,31 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
     hipLaunchKernelGGL(k_msm_accum2c, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
-static void launch_fold_small(hipStream_t s, bool four, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
-    if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
+static void launch_fold_small(hipStream_t s, bool four, bool limb, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    if (limb)
+        hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
+    else if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
         hipLaunchKernelGGL(k_msm_fold_small4<Fp>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
     else
         hipLaunchKernelGGL(k_msm_fold_small<Fp>, dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
 }
-static void launch_fold_small(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+static void launch_fold_small(hipStream_t s, bool, bool, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
     hipLaunchKernelGGL(k_msm_fold_small8c, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
 }
-static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, const Xyzz<Fp> *partial, const uint32_t *taskoff,
+static void launch_fold_big(hipStream_t s, bool limb, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    if (limb) hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+    else hipLaunchKernelGGL(k_msm_fold_big<Fp>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+}
+static void launch_fold_big(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    hipLaunchKernelGGL(k_msm_fold_big<Fp2>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+}
+static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout) {
-    if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    if (limb) hipLaunchKernelGGL((k_msm_reduce1<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    else if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
-static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
+static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
@@ -958,7 +973,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // G1 plans that take the one-lane accumulate run it in limb form (limb30.h): the decode kernel
     // writes 168-byte limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernel.
     static const bool env_limb = [] { const char *v = getenv("EIP2537_LIMB_FORM"); return !v || atoi(v) != 0; }();
-    const bool limb_form = !ReduceCfg<F>::kFourLane && pl.c > 13 && env_limb;
+    const bool limb_form = !ReduceCfg<F>::kFourLane && pl.c > 13 && !four && env_limb;
     HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
@@ -970,7 +985,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
-    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
+    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
@@ -1033,9 +1048,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
     launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    launch_fold_small(s, four, partial, taskoff, split_small, totals + 2);
-    hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
-    launch_reduce(s, red_blocks, four, partial, taskoff, pl, rg, winout);
+    launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
+    launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
+    launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
@@ -1234,7 +1249,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     HIPCHK(hipEventRecord(e->ev_a, s));
     launch_accum(s, task_blocks, true, pts, nullptr, entries, tasks, perm, totals, partial);      // two lanes per task
     HIPCHK(hipEventRecord(e->ev_b, s));
-    launch_fold_small(s, true, partial, taskoff, split_small, totals + 2);
+    launch_fold_small(s, true, false, partial, taskoff, split_small, totals + 2);
     hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
     if (units * 4u <= 1024u)       // one block per unit while 4 waves per unit fit one round of one wave per SIMD
         hipLaunchKernelGGL((k_msm_reduce_batch<F, 4>), dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);

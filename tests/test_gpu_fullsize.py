@@ -140,6 +140,20 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
         assert clib.call("bls12_g1multiexp", same) == (0, got), k
     assert X.g1_mul(ones + m.encode_scalar(2 ** 256 - 1)) == X.g1_multiexp(
         b"".join(base[i * 160:i * 160 + 128] + m.encode_scalar(2 ** 256 - 1) for i in range(m20)))
+    # the same shapes through the plan of the large sizes (c = 16: limb-form accumulate, fold and reduce,
+    # csrc/limb30.h): one bucket per window with all 20000 records (k_msm_fold_big), and scalars from a set
+    # of 97 values, ~200 records = 4 tasks per bucket (k_msm_fold_small)
+    X.set_window(16)
+    try:
+        same = b"".join(base[i * 160:i * 160 + 128] + m.encode_scalar(2 ** 256 - 1) for i in range(m20))
+        assert clib.call("bls12_g1multiexp", same) == (0, X.g1_multiexp(same))
+        assert X.last_plan()["kernel"] == "k_msm_accum_l"
+        rng = m.SplitMix64(97)
+        pool = [rng.scalar256() for _ in range(97)]
+        few = b"".join(base[i * 160:i * 160 + 128] + m.encode_scalar(pool[(i * 31) % 97]) for i in range(m20))
+        assert clib.call("bls12_g1multiexp", few) == (0, X.g1_multiexp(few))
+    finally:
+        X.set_window(0)
     # G2 with a heavy top window
     inp = X.gen_msm_input("g2", 1 << 12, A, B, 1212)
     assert call_x(X.g2_multiexp, inp) == clib.call("bls12_g2multiexp", inp)

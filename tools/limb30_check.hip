@@ -75,5 +75,33 @@ int main() {
         if (!eq(canon_of(acc.x), ref.x) || !eq(canon_of(acc.y), ref.y) || !eq(canon_of(acc.zz), ref.zz) || !eq(canon_of(acc.zzz), ref.zzz)) bad2++;
     }
     printf("accumulate chains: %ld mismatches\n", bad2);
+    // complete additions and doublings of limb-form points (fold / reduce kernels) against curve.h
+    long bad3 = 0;
+    auto lift = [&](const Xyzz<Fp> &v) {
+        return Xyzz<FpL>{fpl_from_mont(v.x), fpl_from_mont(v.y), fpl_from_mont(v.zz), fpl_from_mont(v.zzz)};
+    };
+    auto same = [&](const Xyzz<FpL> &l, const Xyzz<Fp> &v) {
+        if (is_inf(v)) return is_zero(l.zz);
+        const Xyzz<Fp> c = canon(l);
+        return eq(c.x, v.x) && eq(c.y, v.y) && eq(c.zz, v.zz) && eq(c.zzz, v.zzz);
+    };
+    for (int it = 0; it < 20000; it++) {
+        Xyzz<Fp> a{rnd_fp(), rnd_fp(), rnd_fp(), rnd_fp()}, b{rnd_fp(), rnd_fp(), rnd_fp(), rnd_fp()};
+        const uint64_t r = rnd();
+        if (r % 7 == 0) b = a;                                   // doubling through add
+        if (r % 7 == 1) b = neg(a);                              // cancellation
+        if (r % 7 == 2) a = xyzz_inf<Fp>();
+        if (r % 7 == 3) b = xyzz_inf<Fp>();
+        Xyzz<FpL> la = lift(a), lb = lift(b);
+        Xyzz<Fp> ra = a;
+        for (int step = 0; step < 6; step++) {                   // a chain, so that grown bounds feed back
+            if (!same(la, ra)) { bad3++; break; }
+            if ((r >> (8 + step)) & 1) { la = add(la, lb); ra = add(ra, b); }
+            else { la = dbl(la); ra = dbl(ra); }
+        }
+        if (!same(la, ra)) bad3++;
+    }
+    printf("point operations: %ld mismatches\n", bad3);
+    bad2 += bad3;
     return bad || bad2 ? 1 : 0;
 }
