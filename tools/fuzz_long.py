@@ -73,9 +73,13 @@ def main():
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mid", action="store_true", help="mid-size MSMs (2 049 .. 20 000 records) instead of small calls")
+    ap.add_argument("--window", type=int, default=0, help="force the Pippenger window width of the GPU plans (16: the limb-form "
+                    "kernels of the large sizes on these small inputs; the width applies to G1 and G2)")
     args = ap.parse_args()
     global MID
     MID = args.mid
+    if args.window:
+        X.set_window(args.window)
     stop = time.time() + args.seconds
     lock = threading.Lock()
     stats = {"cases": 0, "bad": [], "by_op": {}, "errors_seen": {}}
