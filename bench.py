@@ -334,8 +334,8 @@ def main():
                 tj.get("kernel", plan.get("kernel")) == plan.get("kernel"):
             traffic = tj["traffic_bytes_raw"]
             traffic_note = ("PMC (FETCH_SIZE+WRITE_SIZE)*1024 per launch, raw; %.3g with the gfx950 x2 FETCH correction "
-                            "(calibrated for coalesced streams only; this kernel gathers 96-B points, one pass per window "
-                            "over a 101 MB point array that stays in the 256 MB Infinity Cache). Source: profiles/%s"
+                            "(calibrated for coalesced streams only; this kernel gathers 104-B limb records at a 168-B stride, one pass "
+                            "per window over a 176 MB point array that stays in the 256 MB Infinity Cache). Source: profiles/%s"
                             % (tj["traffic_bytes_fetch_x2"], tj.get("source", tname)))
         break
 
@@ -381,6 +381,13 @@ def main():
                 "note": "algorithmic Fp products = records x windows (%d, c = %d) x 10 (x3 over Fp2), %d multiply-adds each; "
                         "peak = chip-wide v_mad_u64_u32 rate measured by tools/valu_probe.hip (profiles/r01_valu_probe.txt)"
                         % (plan["windows"], plan.get("window_bits", 0), MADS_PER_FP_PRODUCT)}
+            # multiply-adds the G1 kernels really execute per mixed addition: the two squarings take 260 of them
+            # (91 + 169), and the limb-form kernel reduces R (Q - x3) - y1 PPP once (338 + 169)
+            executed = {"k_msm_accum_l": 6 * 338 + 2 * 260 + 507, "k_msm_accum<eip::Fp>": 8 * 338 + 2 * 260,
+                        "k_msm_accum2<eip::Fp>": 8 * 338 + 2 * 260}.get(plan.get("kernel"))
+            if executed:
+                result["roofline_valu"]["mads_executed_per_addition"] = executed
+                result["roofline_valu"]["frac_executed"] = n_local * plan["windows"] * executed / (k_ms * 1e-3) / MAD_PEAK
 
     # ---- the reference-ABI call itself: host buffer in, H2D inside the timed call
     if rank == 0 and world == 1 and not args.no_host_abi:
