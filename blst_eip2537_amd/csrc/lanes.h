@@ -31,6 +31,64 @@ __device__ __forceinline__ Fp2 shfl_from(const Fp2 &a, int src) { return Fp2{shf
 template <class T> __device__ __forceinline__ Xyzz<T> shfl_from(const Xyzz<T> &p, int src) {
     return Xyzz<T>{shfl_from(p.x, src), shfl_from(p.y, src), shfl_from(p.zz, src), shfl_from(p.zzz, src)};
 }
+// Value of lane J of the caller's aligned 4-lane group: a DPP quad_perm broadcast -- one VALU move per dword,
+// no LDS round trip (ds_bpermute) in the chain-bound 4-lane kernels.  EIP_QUAD_DPP=0 builds the shuffle form.
+#ifndef EIP_QUAD_DPP
+#define EIP_QUAD_DPP 1
+#endif
+template <int J> __device__ __forceinline__ Fp quad_from(const Fp &a) {
+    Fp r;
+#if EIP_QUAD_DPP
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], J * 0x55, 0xf, 0xf, true);
+#else
+    const int src = (threadIdx.x & 60) + J;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = __shfl(a.l[i], src, 64);
+#endif
+    return r;
+}
+template <int J> __device__ __forceinline__ FpI quad_from(const FpI &a) { return FpI{quad_from<J>(a.v)}; }
+// the same for an arbitrary quad permutation: PAIR0 / PAIR1 = lane 0 / 1 of the caller's aligned lane pair,
+// SWAP = the partner lane (lane ^ 1)
+static constexpr int kDppPair0 = 0xA0, kDppPair1 = 0xF5, kDppSwap = 0xB1;
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+#if EIP_QUAD_DPP
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+#else
+    const int l = threadIdx.x & 63;
+    return __shfl(v, (l & 60) + ((CTRL >> (2 * (l & 3))) & 3), 64);
+#endif
+}
+template <int CTRL> __device__ __forceinline__ Fp quad_perm(const Fp &a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = quad_perm<CTRL>(a.l[i]);
+    return r;
+}
+template <int CTRL> __device__ __forceinline__ FpI quad_perm(const FpI &a) { return FpI{quad_perm<CTRL>(a.v)}; }
+template <int CTRL> __device__ __forceinline__ Fp2 quad_perm(const Fp2 &a) { return Fp2{quad_perm<CTRL>(a.c0), quad_perm<CTRL>(a.c1)}; }
+// Value of lane 2 J + (own parity) of the caller's aligned 8-lane group (J = 0 .. 3: the lane pair): the pair is
+// first broadcast inside each quad, then the quad that does not hold it takes the other quad's copy with a
+// row shift by 4 restricted to its own banks -- two VALU moves per dword instead of a ds_bpermute.
+template <int J> __device__ __forceinline__ uint32_t group8_pair(uint32_t v) {
+#if EIP_QUAD_DPP
+    const int t = __builtin_amdgcn_mov_dpp((int)v, (J & 1) ? 0xEE : 0x44, 0xf, 0xf, true);
+    if (J < 2) return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xA, false);    // row_shr:4 into lanes 4..7, 12..15
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);               // row_shl:4 into lanes 0..3, 8..11
+#else
+    const int l = threadIdx.x & 63;
+    return __shfl(v, (l & 56) + 2 * J + (l & 1), 64);
+#endif
+}
+template <int J> __device__ __forceinline__ FpI group8_pair(const FpI &a) {
+    FpI r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v.l[i] = group8_pair<J>(a.v.l[i]);
+    return r;
+}
+
+template <int J> __device__ __forceinline__ Fp2 quad_from(const Fp2 &a) { return Fp2{quad_from<J>(a.c0), quad_from<J>(a.c1)}; }
 // value of lane + off (lanes past the end read their own value; callers mask them out)
 template <class T> __device__ __forceinline__ T shfl_down(const T &a, int off) {
     const int lane = threadIdx.x & 63;
@@ -81,14 +139,14 @@ struct PairProd8 {
     __device__ __forceinline__ Prod4c operator()(const FpI &a0, const FpI &a1, const FpI &a2, const FpI &a3,
                                                  const FpI &b0, const FpI &b1, const FpI &b2, const FpI &b3) const {
         const FpI u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);     // own components of this pair's operands
-        const FpI up = shfl_from(u, lane ^ 1), vp = shfl_from(v, lane ^ 1);     // the partner's
+        const FpI up = quad_perm<kDppSwap>(u), vp = quad_perm<kDppSwap>(v);         // the partner's
         // q = 0: c0 = u0 v0 - u1 v1      q = 1: c1 = u0 v1 + u1 v0
         const FpI m1 = mul(sel2(q, u, up), v), m2 = mul(sel2(q, up, u), vp);
         const FpI c = q ? add(m1, m2) : sub(m1, m2);
-        return Prod4c{shfl_from(c, gbase + q), shfl_from(c, gbase + 2 + q), shfl_from(c, gbase + 4 + q), shfl_from(c, gbase + 6 + q)};
+        return Prod4c{group8_pair<0>(c), group8_pair<1>(c), group8_pair<2>(c), group8_pair<3>(c)};
     }
     // an Fp2 predicate holds when it holds on both components
-    __device__ __forceinline__ bool both(bool mine) const { const int m = mine ? 1 : 0; return (m & __shfl(m, lane ^ 1, 64)) != 0; }
+    __device__ __forceinline__ bool both(bool mine) const { const uint32_t m = mine ? 1u : 0u; return (m & quad_perm<kDppSwap>(m)) != 0; }
 };
 // A point over Fp2 seen from one lane: Xyzz<FpI> holding this lane's component of each coordinate.
 __device__ __forceinline__ Xyzz<FpI> component_of(const Xyzz<Fp2> &p, int q) {

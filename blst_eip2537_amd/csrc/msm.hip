@@ -406,21 +406,21 @@ template <class T> __device__ __forceinline__ Xyzz<T> madd2(const Xyzz<T> &p, co
     if (is_inf(q)) return p;                                   // uniform in the pair of lanes
     if (is_inf(p)) return Xyzz<T>{q.x, q.y, f_one<T>(), f_one<T>()};
     T pr = hmul<2>(sel2(r, q.x, q.y), sel2(r, p.zz, p.zzz));
-    const T U2 = shfl_from(pr, gb), S2 = shfl_from(pr, gb + 1);
+    const T U2 = quad_perm<kDppPair0>(pr), S2 = quad_perm<kDppPair1>(pr);
     const T Pd = sub(U2, p.x), Rr = sub(S2, p.y);
     if (is_zero(Pd)) {
         if (is_zero(Rr)) return dbl_affine(q);
         return xyzz_inf<T>();
     }
     pr = hmul<2>(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
-    const T PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1);
+    const T PP = quad_perm<kDppPair0>(pr), RR = quad_perm<kDppPair1>(pr);
     pr = hmul<2>(sel2(r, Pd, p.x), PP);
-    const T PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1);
+    const T PPP = quad_perm<kDppPair0>(pr), Q = quad_perm<kDppPair1>(pr);
     const T X3 = sub(sub(RR, PPP), dbl(Q));
     pr = hmul<2>(sel2(r, p.zz, p.y), sel2(r, PP, PPP));
-    const T ZZ3 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1);
+    const T ZZ3 = quad_perm<kDppPair0>(pr), t1 = quad_perm<kDppPair1>(pr);
     pr = hmul<2>(sel2(r, Rr, p.zzz), sel2(r, sub(Q, X3), PPP));
-    const T t0 = shfl_from(pr, gb), ZZZ3 = shfl_from(pr, gb + 1);
+    const T t0 = quad_perm<kDppPair0>(pr), ZZZ3 = quad_perm<kDppPair1>(pr);
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // G1 for the plans whose accumulate is a chain rather than a stream (c <= 13, up to 2^17 records: the
@@ -456,17 +456,17 @@ struct Pair2c { FpI r0, r1; };                    // this lane's component of th
 __device__ __forceinline__ Pair2c prod2c(const FpI &a0, const FpI &b0, const FpI &a1, const FpI &b1, int r, int lane) {
     // my product is (a_r, b_r); the partner needs my component of (a_{1-r}, b_{1-r})
     const FpI mine_u = sel2(r, a0, a1), mine_v = sel2(r, b0, b1);
-    const FpI other_u = shfl_from(sel2(r, a1, a0), lane ^ 1), other_v = shfl_from(sel2(r, b1, b0), lane ^ 1);
+    const FpI other_u = quad_perm<kDppSwap>(sel2(r, a1, a0)), other_v = quad_perm<kDppSwap>(sel2(r, b1, b0));
     // lane r holds component r: (u0, u1) = r ? (other, mine) : (mine, other)
     const FpI u0 = sel2(r, mine_u, other_u), u1 = sel2(r, other_u, mine_u);
     const FpI v0 = sel2(r, mine_v, other_v), v1 = sel2(r, other_v, mine_v);
     const FpI t0 = mul(u0, v0), t1 = mul(u1, v1), t2 = mul(add(u0, u1), add(v0, v1));
     const FpI c0 = sub(t0, t1), c1 = sub(sub(t2, t0), t1);
     // keep my component of my product, fetch my component of the partner's product
-    const FpI keep = sel2(r, c0, c1), got = shfl_from(sel2(r, c1, c0), lane ^ 1);
+    const FpI keep = sel2(r, c0, c1), got = quad_perm<kDppSwap>(sel2(r, c1, c0));
     return Pair2c{sel2(r, keep, got), sel2(r, got, keep)};
 }
-__device__ __forceinline__ bool both2(bool mine, int lane) { const int m = mine ? 1 : 0; return (m & __shfl(m, lane ^ 1, 64)) != 0; }
+__device__ __forceinline__ bool both2(bool mine, int) { const uint32_t m = mine ? 1u : 0u; return (m & quad_perm<kDppSwap>(m)) != 0; }
 // 2Q for affine Q != infinity (mdbl-2008-s-1), components
 __device__ __forceinline__ Xyzz<FpI> dbl_affine2c(const Aff<FpI> &a, int r, int lane) {
     const FpI U = dbl(a.y);
@@ -653,32 +653,32 @@ template <class T> __device__ __forceinline__ Xyzz<T> add4(const Xyzz<T> &p, con
     if (qinf) return p;
     if (pinf) return q;
     T pr = hmul<EIP_G2_HOT_RED>(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
-    const T U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
+    const T U1 = quad_from<0>(pr), U2 = quad_from<1>(pr), S1 = quad_from<2>(pr), S2 = quad_from<3>(pr);
     const T Pd = sub(U2, U1), Rr = sub(S2, S1);
     if (is_zero(Pd)) {                                         // same x: double or cancel (rare)
         if (is_zero(Rr)) return dbl(p);
         return xyzz_inf<T>();
     }
     pr = hmul<EIP_G2_HOT_RED>(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
-    const T PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
+    const T PP = quad_from<0>(pr), RR = quad_from<1>(pr), ZZ12 = quad_from<2>(pr), ZZZ12 = quad_from<3>(pr);
     pr = hmul<EIP_G2_HOT_RED>(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
-    const T PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
+    const T PPP = quad_from<0>(pr), Q = quad_from<1>(pr), ZZ3 = quad_from<2>(pr);
     const T X3 = sub(sub(RR, PPP), dbl(Q));
     pr = hmul<EIP_G2_HOT_RED>(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
-    const T t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    const T t0 = quad_from<0>(pr), t1 = quad_from<1>(pr), ZZZ3 = quad_from<2>(pr);
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // 2P (dbl-2008-s-1); infinity stays infinity
 template <class T> __device__ __forceinline__ Xyzz<T> dbl4(const Xyzz<T> &p, int r, int gb) {
     const T U = dbl(p.y);
     T pr = hmul<EIP_G2_HOT_RED>(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
-    const T V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
+    const T V = quad_from<0>(pr), XX = quad_from<1>(pr);
     const T M = add(dbl(XX), XX);
     pr = hmul<EIP_G2_HOT_RED>(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
-    const T W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
+    const T W = quad_from<0>(pr), S = quad_from<1>(pr), MM = quad_from<2>(pr), ZZ3 = quad_from<3>(pr);
     const T X3 = sub(MM, dbl(S));
     pr = hmul<EIP_G2_HOT_RED>(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
-    const T t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    const T t0 = quad_from<0>(pr), t1 = quad_from<1>(pr), ZZZ3 = quad_from<2>(pr);
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &p, uint32_t m, int r, int gb) {

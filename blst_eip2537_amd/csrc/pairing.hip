@@ -62,32 +62,32 @@ __device__ __forceinline__ Xyzz<FpI> g1_add4(const Xyzz<FpI> &p, const Xyzz<FpI>
     if (is_inf(q)) return p;                                  // uniform in the group
     if (is_inf(p)) return q;
     FpI pr = mul(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));
-    const FpI U1 = shfl_from(pr, gb), U2 = shfl_from(pr, gb + 1), S1 = shfl_from(pr, gb + 2), S2 = shfl_from(pr, gb + 3);
+    const FpI U1 = quad_from<0>(pr), U2 = quad_from<1>(pr), S1 = quad_from<2>(pr), S2 = quad_from<3>(pr);
     const FpI Pd = sub(U2, U1), Rr = sub(S2, S1);
     if (is_zero(Pd)) {                                        // same x: double or cancel (small-order inputs)
         if (is_zero(Rr)) return dbl(p);
         return xyzz_inf<FpI>();
     }
     pr = mul(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
-    const FpI PP = shfl_from(pr, gb), RR = shfl_from(pr, gb + 1), ZZ12 = shfl_from(pr, gb + 2), ZZZ12 = shfl_from(pr, gb + 3);
+    const FpI PP = quad_from<0>(pr), RR = quad_from<1>(pr), ZZ12 = quad_from<2>(pr), ZZZ12 = quad_from<3>(pr);
     pr = mul(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
-    const FpI PPP = shfl_from(pr, gb), Q = shfl_from(pr, gb + 1), ZZ3 = shfl_from(pr, gb + 2);
+    const FpI PPP = quad_from<0>(pr), Q = quad_from<1>(pr), ZZ3 = quad_from<2>(pr);
     const FpI X3 = sub(sub(RR, PPP), dbl(Q));
     pr = mul(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, sub(Q, X3), PPP, PPP, PPP));
-    const FpI t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    const FpI t0 = quad_from<0>(pr), t1 = quad_from<1>(pr), ZZZ3 = quad_from<2>(pr);
     return Xyzz<FpI>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // 2P (dbl-2008-s-1); infinity stays infinity (zz = 0 propagates)
 __device__ __forceinline__ Xyzz<FpI> g1_dbl4(const Xyzz<FpI> &p, int r, int gb) {
     const FpI U = dbl(p.y);
     FpI pr = mul(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));
-    const FpI V = shfl_from(pr, gb), XX = shfl_from(pr, gb + 1);
+    const FpI V = quad_from<0>(pr), XX = quad_from<1>(pr);
     const FpI M = add(dbl(XX), XX);
     pr = mul(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));
-    const FpI W = shfl_from(pr, gb), S = shfl_from(pr, gb + 1), MM = shfl_from(pr, gb + 2), ZZ3 = shfl_from(pr, gb + 3);
+    const FpI W = quad_from<0>(pr), S = quad_from<1>(pr), MM = quad_from<2>(pr), ZZ3 = quad_from<3>(pr);
     const FpI X3 = sub(MM, dbl(S));
     pr = mul(sel4(r, M, W, W, W), sel4(r, sub(S, X3), p.y, p.zzz, p.zzz));
-    const FpI t0 = shfl_from(pr, gb), t1 = shfl_from(pr, gb + 1), ZZZ3 = shfl_from(pr, gb + 2);
+    const FpI t0 = quad_from<0>(pr), t1 = quad_from<1>(pr), ZZZ3 = quad_from<2>(pr);
     return Xyzz<FpI>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 // [|z|]p on the 4 lanes of the group
