@@ -588,6 +588,108 @@ __device__ __forceinline__ FpL shfl_from(const FpL &a, int src) {
     for (int i = 0; i < 13; i++) r.l[i] = __shfl(a.l[i], src, 64);
     return r;
 }
+__device__ __forceinline__ FpL sel4(int r, const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
+    FpL o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
+    return o;
+}
+__device__ __forceinline__ FpL sel2(int r, const FpL &a, const FpL &b) {
+    FpL o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = r == 0 ? a.l[i] : b.l[i];
+    return o;
+}
+template <int CTRL> __device__ __forceinline__ FpL quad_perm(const FpL &a) {
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = quad_perm<CTRL>(a.l[i]);
+    return r;
+}
+template <int J> __device__ __forceinline__ FpL quad_from(const FpL &a) { return quad_perm<J * 0x55>(a); }
+
+// ---- limb-form versions of the lane-split point operations (chain-bound G1 plans, c <= 13) -----------
+// Same rounds as add4 / dbl4 / madd2 below and above; values are FpL with the standard bounds of limb30.h
+// (x < 8, y < 4, zz, zzz < 2 in units of p), differences are a + K p - b.
+// P + Q (add-2008-s), operands replicated on the 4 lanes of the group, complete
+__device__ __forceinline__ Xyzz<FpL> dbl4(const Xyzz<FpL> &p, int r, int gb);
+__device__ __forceinline__ Xyzz<FpL> add4(const Xyzz<FpL> &p, const Xyzz<FpL> &q, int r, int gb) {
+    if (is_zero(q.zz)) return p;                               // uniform in the group
+    if (is_zero(p.zz)) return q;
+    FpL pr = mulL(sel4(r, p.x, q.x, p.y, q.y), sel4(r, q.zz, p.zz, q.zzz, p.zzz));        // 16, 16, 8, 8 < 630
+    const FpL U1 = quad_from<0>(pr), U2 = quad_from<1>(pr), S1 = quad_from<2>(pr), S2 = quad_from<3>(pr);
+    const FpL Pd = subL<2>(U2, U1), Rr = subL<2>(S2, S1);       // < 4
+    if (is_zero_modp(Pd, 4)) {                                  // same x: double or cancel (rare)
+        if (is_zero_modp(Rr, 4)) return dbl4(p, r, gb);
+        return xyzz_inf<FpL>();
+    }
+    pr = mulL(sel4(r, Pd, Rr, p.zz, p.zzz), sel4(r, Pd, Rr, q.zz, q.zzz));
+    const FpL PP = quad_from<0>(pr), RR = quad_from<1>(pr), ZZ12 = quad_from<2>(pr), ZZZ12 = quad_from<3>(pr);
+    pr = mulL(sel4(r, Pd, U1, ZZ12, ZZ12), PP);
+    const FpL PPP = quad_from<0>(pr), Q = quad_from<1>(pr), ZZ3 = quad_from<2>(pr);
+    const FpL X3 = sub2L<4>(subL<2>(RR, PPP), Q);               // < 8
+    pr = mulL(sel4(r, Rr, S1, ZZZ12, ZZZ12), sel4(r, subL<8>(Q, X3), PPP, PPP, PPP));      // 4 x 10, 2 x 2
+    const FpL t0 = quad_from<0>(pr), t1 = quad_from<1>(pr), ZZZ3 = quad_from<2>(pr);
+    return Xyzz<FpL>{X3, subL<2>(t0, t1), ZZ3, ZZZ3};
+}
+// 2P (dbl-2008-s-1); infinity stays infinity (zz = 0 propagates)
+__device__ __forceinline__ Xyzz<FpL> dbl4(const Xyzz<FpL> &p, int r, int gb) {
+    const FpL U = addL(p.y, p.y);                              // < 8
+    FpL pr = mulL(sel4(r, U, p.x, U, U), sel4(r, U, p.x, U, U));                           // 64, 64
+    const FpL V = quad_from<0>(pr), XX = quad_from<1>(pr);
+    const FpL M = dbl_addL(XX, XX);                            // < 6
+    pr = mulL(sel4(r, U, p.x, M, V), sel4(r, V, V, M, p.zz));  // 16, 16, 36, 4
+    const FpL W = quad_from<0>(pr), S = quad_from<1>(pr), MM = quad_from<2>(pr), ZZ3 = quad_from<3>(pr);
+    const FpL X3 = sub2L<4>(MM, S);                            // < 6
+    pr = mulL(sel4(r, M, W, W, W), sel4(r, subL<6>(S, X3), p.y, p.zzz, p.zzz));            // 6 x 8, 2 x 4, 2 x 2
+    const FpL t0 = quad_from<0>(pr), t1 = quad_from<1>(pr), ZZZ3 = quad_from<2>(pr);
+    return Xyzz<FpL>{X3, subL<2>(t0, t1), ZZ3, ZZZ3};
+}
+// acc += (qx, qy) on the two lanes of a task: the rounds of madd2, [U2 S2] [PP RR] [PPP Q] [ZZ3 Y1*PPP] [R*(Q-X3) ZZZ3]
+__device__ __forceinline__ void madd2_l(AccL &acc, bool &inf, const FpL &qx, const FpL &qy, int r) {
+    if (inf) {                                                 // uniform in the pair of lanes
+        acc = AccL{qx, qy, fpl_one(), fpl_one()};
+        inf = false;
+        return;
+    }
+    FpL pr = mulL(sel2(r, qx, qy), sel2(r, acc.zz, acc.zzz));
+    const FpL U2 = quad_perm<kDppPair0>(pr), S2 = quad_perm<kDppPair1>(pr);
+    const FpL Pd = subL<8>(U2, acc.x), Rr = subL<4>(S2, acc.y);                            // < 10, < 6
+    if (is_zero_modp(Pd, 10)) {
+        if (is_zero_modp(Rr, 6)) acc = dbl_affine_l(qx, qy);
+        else inf = true;
+        return;
+    }
+    pr = mulL(sel2(r, Pd, Rr), sel2(r, Pd, Rr));
+    const FpL PP = quad_perm<kDppPair0>(pr), RR = quad_perm<kDppPair1>(pr);
+    pr = mulL(sel2(r, Pd, acc.x), PP);
+    const FpL PPP = quad_perm<kDppPair0>(pr), Q = quad_perm<kDppPair1>(pr);
+    const FpL X3 = sub2L<4>(subL<2>(RR, PPP), Q);               // < 8
+    pr = mulL(sel2(r, acc.zz, acc.y), sel2(r, PP, PPP));
+    const FpL ZZ3 = quad_perm<kDppPair0>(pr), t1 = quad_perm<kDppPair1>(pr);
+    pr = mulL(sel2(r, Rr, acc.zzz), sel2(r, subL<8>(Q, X3), PPP));                         // 6 x 10, 2 x 2
+    const FpL t0 = quad_perm<kDppPair0>(pr), ZZZ3 = quad_perm<kDppPair1>(pr);
+    acc = AccL{X3, subL<2>(t0, t1), ZZ3, ZZZ3};
+}
+// two lanes per task (the chain-bound G1 plans), limb form: the counterpart of k_msm_accum2<Fp>
+__global__ void __launch_bounds__(256)
+k_msm_accum2_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
+               const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp> *__restrict__ partial_) {
+    Xyzz<FpL> *__restrict__ partial = reinterpret_cast<Xyzz<FpL> *>(partial_);
+    const int lane = threadIdx.x & 63, r = lane & 1;
+    const uint32_t slot = blockIdx.x * 128u + (threadIdx.x >> 1);
+    if (slot >= totals[1]) return;                             // uniform in the pair
+    const uint32_t t = perm[slot];
+    const Task tk = tasks[t];
+    AccL acc;
+    bool inf = true;
+    for (uint32_t e = 0; e < tk.len; e++) {
+        const uint32_t ent = entries[tk.start + e];
+        const PtL *q = &pts[ent >> 1];
+        madd2_l(acc, inf, load_limbs(q->x), load_limbs((ent & 1u) ? q->ny : q->y), r);
+    }
+    if (r == 0) partial[t] = inf ? xyzz_inf<FpL>() : Xyzz<FpL>{acc.x, acc.y, acc.zz, acc.zzz};
+}
 // per-block window sums leave the device in the canonical form the host reads, whatever the kernel computed in
 template <class F, class T> __device__ __forceinline__ void store_canon(Xyzz<F> *out, const Xyzz<T> &v) { *reinterpret_cast<Xyzz<T> *>(out) = canon(v); }
 template <> __device__ __forceinline__ void store_canon<Fp, FpL>(Xyzz<Fp> *out, const Xyzz<FpL> &v) { *out = canon(v); }
@@ -692,11 +794,10 @@ template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &
 
 // fold of lightly split buckets with 4-lane additions (G2: the one-lane chain of 1-7 Fp2 additions
 // on a few hundred lanes cost 0.19 ms at 2^16, where the 9-bit top window holds 128 records per bucket)
-template <class F>
+template <class F, class T = typename AccumField<F>::T>    // T: the form the accumulate kernel wrote the partials in
 __global__ void __launch_bounds__(256)
 k_msm_fold_small4(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                   const uint32_t *__restrict__ split_counts) {
-    using T = typename AccumField<F>::T;              // G1: FpI, like the kernel that wrote the partials
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
     const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
@@ -719,13 +820,11 @@ __device__ __forceinline__ void reduce_block_to_window(const ReduceGrid &rg, con
     else { w = pl.W - 1; bx = b - body; }
 }
 // 256 threads = 64 four-lane groups, one segment of S buckets per group
-template <class F>
+template <class F, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256, 1)      // latency-bound chain: registers over occupancy
 k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
-             Xyzz<F> *__restrict__ winout_) {
-    using T = typename AccumField<F>::T;
+             Xyzz<F> *__restrict__ winout) {
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
-    Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
     int w;
     uint32_t bx;
     reduce_block_to_window(rg, pl, w, bx);
@@ -757,7 +856,7 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (wave == 0 && lane < 4) {
         for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
-        if (lane == 0) winout[blockIdx.x] = canon(C);
+        if (lane == 0) store_canon<F, T>(&winout[blockIdx.x], C);
     }
 }
 
@@ -874,7 +973,9 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
 
 static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const PtL *ptl, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
-    if (chain_bound)
+    if (chain_bound && ptl)
+        hipLaunchKernelGGL(k_msm_accum2_l, dim3(task_blocks * 2u), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial);
+    else if (chain_bound)
         hipLaunchKernelGGL(k_msm_accum2<Fp>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
     else if (ptl)
         hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial);
@@ -886,7 +987,9 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp
     hipLaunchKernelGGL(k_msm_accum2c, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
 static void launch_fold_small(hipStream_t s, bool four, bool limb, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
-    if (limb)
+    if (limb && four)
+        hipLaunchKernelGGL((k_msm_fold_small4<Fp, FpL>), dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+    else if (limb)
         hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
     else if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
         hipLaunchKernelGGL(k_msm_fold_small4<Fp>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
@@ -905,7 +1008,8 @@ static void launch_fold_big(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint3
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout) {
-    if (limb) hipLaunchKernelGGL((k_msm_reduce1<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    if (limb && four) hipLaunchKernelGGL((k_msm_reduce4<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    else if (limb) hipLaunchKernelGGL((k_msm_reduce1<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
@@ -970,10 +1074,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     const size_t nwin_out = red_blocks;
 
-    // G1 plans that take the one-lane accumulate run it in limb form (limb30.h): the decode kernel
-    // writes 168-byte limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernel.
+    // G1 plans run accumulate, fold and reduce in limb form (limb30.h): the decode kernel writes 168-byte
+    // limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernels.
     static const bool env_limb = [] { const char *v = getenv("EIP2537_LIMB_FORM"); return !v || atoi(v) != 0; }();
-    const bool limb_form = !ReduceCfg<F>::kFourLane && pl.c > 13 && !four && env_limb;
+    const bool limb_form = !ReduceCfg<F>::kFourLane && env_limb && (pl.c > 13 ? !four : four);     // G1: (one lane, reduce1) or (two lanes, reduce4)
     HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
@@ -1019,7 +1123,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
         LastPlan lp{};
         if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");        // G2: split by component
-        else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum_l");
+        else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, two_lane ? "k_msm_accum2_l" : "k_msm_accum_l");
         else snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
         lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB;
         e->last_plan = lp;
