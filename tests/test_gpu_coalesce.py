@@ -54,13 +54,25 @@ def test_concurrent_small_g1_calls_are_coalesced_and_exact(X, clib):
     jobs.append((X.g1_multiexp, bytes(bad), (1, None)))
     bad[7 * 160 + 2] = 1                                                                  # record 7 pad byte wins
     jobs.append((X.g1_multiexp, bytes(bad), (3, None)))
+    # GPU route pinned: by default calls of up to 16 records run the library's host code (the crossover,
+    # tests/test_gpu_routes.py) and would never reach the queue -- the tiny adversarial calls above are here
+    # to ride in coalesced batches
+    X.set_route(0)
+    try:
+        before = X.coalesce_stats()
+        assert _hammer(jobs) == []
+        pipelines, calls, largest = (b - a for a, b in zip(before, X.coalesce_stats()))
+        queued = sum(1 for _, inp, _ in jobs if 2 <= len(inp) // 160 <= 512)    # above: straight to an engine
+        assert calls == 3 * queued
+        assert pipelines < calls, "no call ever shared a pipeline"
+        assert X.coalesce_stats()[2] >= 2
+    finally:
+        X.set_route(-1)
+    # default route: only the calls above the crossover are queued, the others are served on the host
     before = X.coalesce_stats()
-    assert _hammer(jobs) == []
-    pipelines, calls, largest = (b - a for a, b in zip(before, X.coalesce_stats()))
-    queued = sum(1 for _, inp, _ in jobs if 3 <= len(inp) // 160 <= 512)        # below: the host crossover; above: straight to an engine
-    assert calls == 3 * queued
-    assert pipelines < calls, "no call ever shared a pipeline"
-    assert X.coalesce_stats()[2] >= 2
+    assert _hammer(jobs, rounds=1) == []
+    calls = X.coalesce_stats()[1] - before[1]
+    assert calls == sum(1 for _, inp, _ in jobs if 17 <= len(inp) // 160 <= 512)
 
 
 def test_concurrent_small_g2_and_mixed_calls(X, clib):
@@ -77,6 +89,11 @@ def test_concurrent_small_g2_and_mixed_calls(X, clib):
     pr = clib.gen_pairing_input(4, 5, 7, 11, 13)
     jobs.append((X.pairing, pr, clib.call("bls12_pairing", pr)))
     assert _hammer(jobs) == []
+    X.set_route(0)                                                       # everything on the GPU: the small G2 calls are queued too
+    try:
+        assert _hammer(jobs, rounds=2) == []
+    finally:
+        X.set_route(-1)
 
 
 def _pairing_case(clib, k, seed, delta):
