@@ -422,19 +422,18 @@ template <class F> static int msm_host_small(byte *out, const byte *in, size_t n
 }
 static void pairing_finish(byte *out, const Fp12 &ml);
 static int pairing_host_small(byte *out, const byte *in, size_t k) {
-    Fp12 f = fp12_one();
-    for (size_t i = 0; i < k; i++, in += 384) {
-        Aff<Fp> P;
-        Aff<Fp2> Q;
-        int st = host_decode_point<Fp>(P, in);
+    if (k > kHostRouteTestMax) return E_MEMORY_ERROR;
+    Aff<Fp> P[kHostRouteTestMax];
+    Aff<Fp2> Q[kHostRouteTestMax];
+    for (size_t i = 0; i < k; i++, in += 384) {              // the reference's order of checks, pair by pair (src/eip2537.c:1033-1053)
+        int st = host_decode_point<Fp>(P[i], in);
         if (st) return st;
-        if (!in_g1(P)) return E_NOT_IN_SUBGROUP;
-        st = host_decode_point<Fp2>(Q, in + 128);
+        if (!in_g1(P[i])) return E_NOT_IN_SUBGROUP;
+        st = host_decode_point<Fp2>(Q[i], in + 128);
         if (st) return st;
-        if (!in_g2(Q)) return E_NOT_IN_SUBGROUP;
-        f = mul(f, miller_loop(P, Q));
+        if (!in_g2(Q[i])) return E_NOT_IN_SUBGROUP;
     }
-    pairing_finish(out, f);
+    pairing_finish(out, miller_loop_multi(P, Q, k));          // one chain of squarings for all pairs
     return E_SUCCESS;
 }
 

@@ -147,6 +147,32 @@ HD Fp12 miller_loop(const Aff<Fp> &P, const Aff<Fp2> &Q) {
     return conj(f);
 }
 
+// The product of the Miller functions of n pairs with ONE chain of squarings (host route of small
+// pairing checks: 63 Fp12 squarings per call instead of per pair).  Pairs with a point at infinity are skipped.
+inline Fp12 miller_loop_multi(const Aff<Fp> *P, const Aff<Fp2> *Q, size_t n) {
+    constexpr size_t kMax = 64;
+    MillerT T[kMax];
+    size_t idx[kMax], m = 0;
+    for (size_t i = 0; i < n && m < kMax; i++)
+        if (!is_inf(P[i]) && !is_inf(Q[i])) { T[m] = MillerT{Q[i].x, Q[i].y, fp2_one()}; idx[m++] = i; }
+    Fp12 f = fp12_one();
+    if (m == 0) return f;
+    const uint64_t z = K_Z_ABS;
+    for (int i = 62; i >= 0; i--) {
+        if (i != 62) f = sqr(f);                              // the first square is of one
+        for (size_t j = 0; j < m; j++) {
+            const Line l = miller_dbl_step(T[j]);
+            f = mul_by_014(f, l.a0, mul_fp(l.a1, P[idx[j]].x), mul_fp(l.a4, P[idx[j]].y));
+        }
+        if ((z >> i) & 1ull)
+            for (size_t j = 0; j < m; j++) {
+                const Line l = miller_add_step(T[j], Q[idx[j]]);
+                f = mul_by_014(f, l.a0, mul_fp(l.a1, P[idx[j]].x), mul_fp(l.a4, P[idx[j]].y));
+            }
+    }
+    return conj(f);
+}
+
 // The batched form of the loop above (pairing.hip): with L_s the product over all pairs of their line at
 // step s (68 steps: 63 doublings, 5 additions), the product of the pairs' Miller functions is
 // (...((L_0)^2 L_1)^2 ...), squared before every doubling step, conjugated because z < 0.
