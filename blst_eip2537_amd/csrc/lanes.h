@@ -95,10 +95,17 @@ template <class T> __device__ __forceinline__ T shfl_down(const T &a, int off) {
     return shfl_from(a, lane + off < 64 ? lane + off : lane);
 }
 
+// Selections go through by-value helpers on purpose: "r == 0 ? a.l[i] : b.l[i]" on lvalues is an lvalue
+// conditional -- the compiler selects the ADDRESS and loads afterwards, which pins a, b, ... in scratch
+// memory (k_msm_reduce4 carried 1.1 KB of scratch per lane and wrote 580 MB per launch that way).
+__device__ __forceinline__ uint32_t pick2(bool first, uint32_t a, uint32_t b) { return first ? a : b; }
+__device__ __forceinline__ uint32_t pick4(int r, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return r == 0 ? a : r == 1 ? b : r == 2 ? c : d;
+}
 __device__ __forceinline__ Fp sel4(int r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
     Fp o;
 #pragma unroll
-    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
+    for (int i = 0; i < 12; i++) o.l[i] = pick4(r, a.l[i], b.l[i], c.l[i], d.l[i]);
     return o;
 }
 __device__ __forceinline__ FpI sel4(int r, const FpI &a, const FpI &b, const FpI &c, const FpI &d) { return FpI{sel4(r, a.v, b.v, c.v, d.v)}; }
@@ -108,7 +115,7 @@ __device__ __forceinline__ Fp2 sel4(int r, const Fp2 &a, const Fp2 &b, const Fp2
 __device__ __forceinline__ Fp sel2(int r, const Fp &a, const Fp &b) {
     Fp o;
 #pragma unroll
-    for (int i = 0; i < 12; i++) o.l[i] = r == 0 ? a.l[i] : b.l[i];
+    for (int i = 0; i < 12; i++) o.l[i] = pick2(r == 0, a.l[i], b.l[i]);
     return o;
 }
 __device__ __forceinline__ FpI sel2(int r, const FpI &a, const FpI &b) { return FpI{sel2(r, a.v, b.v)}; }
@@ -116,8 +123,8 @@ __device__ __forceinline__ Fp2 sel2(int r, const Fp2 &a, const Fp2 &b) {
     Fp2 o;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        o.c0.l[i] = r == 0 ? a.c0.l[i] : b.c0.l[i];
-        o.c1.l[i] = r == 0 ? a.c1.l[i] : b.c1.l[i];
+        o.c0.l[i] = pick2(r == 0, a.c0.l[i], b.c0.l[i]);
+        o.c1.l[i] = pick2(r == 0, a.c1.l[i], b.c1.l[i]);
     }
     return o;
 }

@@ -123,6 +123,7 @@ HD bool is_zero_modp(const FpL &a, uint32_t bound) {
     const uint32_t p30[13] = {K_P30};
     uint64_t carry = 0;
     bool same = true;
+#pragma unroll                                          // a rolled loop indexes a.l[] dynamically: the caller's value would live in scratch
     for (int k = 0; k < 13; k++) {
         const uint64_t v = (uint64_t)p30[k] * j + carry;
         same &= (k < 12 ? (uint32_t)v & kM30 : (uint32_t)v) == a.l[k];

@@ -591,13 +591,13 @@ __device__ __forceinline__ FpL shfl_from(const FpL &a, int src) {
 __device__ __forceinline__ FpL sel4(int r, const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
     FpL o;
 #pragma unroll
-    for (int i = 0; i < 13; i++) o.l[i] = r == 0 ? a.l[i] : r == 1 ? b.l[i] : r == 2 ? c.l[i] : d.l[i];
+    for (int i = 0; i < 13; i++) o.l[i] = pick4(r, a.l[i], b.l[i], c.l[i], d.l[i]);
     return o;
 }
 __device__ __forceinline__ FpL sel2(int r, const FpL &a, const FpL &b) {
     FpL o;
 #pragma unroll
-    for (int i = 0; i < 13; i++) o.l[i] = r == 0 ? a.l[i] : b.l[i];
+    for (int i = 0; i < 13; i++) o.l[i] = pick2(r == 0, a.l[i], b.l[i]);
     return o;
 }
 template <int CTRL> __device__ __forceinline__ FpL quad_perm(const FpL &a) {

@@ -323,7 +323,7 @@ __device__ __forceinline__ Fp2 grp_mul(const Fp2 &a, const Fp2 &b, int sub, int 
         Fp2 bj = shfl_from(b, gbase + (j & 7));
         Fp2 t = tmul(ai, bj);
         Fp2 tx = mul_xi(t);
-        acc = add(acc, wrap ? tx : t);
+        acc = add(acc, sel2(wrap ? 0 : 1, tx, t));
     }
     return acc;
 }
@@ -366,8 +366,8 @@ template <int CALLER> static __device__ __noinline__ Fp2 grp_mul_k(Fp2 a, Fp2 b,
     const int cb = odd ? i : (i == 0 ? 2 : i - 1);
     const Fp2 fa1 = shfl_from(out1, gbase + 2 * pa + (i == 1 ? 1 : 0)), fa2 = shfl_from(z2, gbase + 2 * pa);
     const Fp2 fb1 = shfl_from(out1, gbase + 2 * pb + (cb == 1 ? 1 : 0)), fb2 = shfl_from(z2, gbase + 2 * pb);
-    const Fp2 first = i == 2 ? fa2 : fa1;
-    Fp2 second = cb == 2 ? fb2 : fb1;
+    const Fp2 first = sel2(i == 2 ? 0 : 1, fa2, fa1);
+    Fp2 second = sel2(cb == 2 ? 0 : 1, fb2, fb1);
     const Fp2 sxi = mul_xi(second);
     if (!odd && i == 0) second = sxi;
     return add(first, second);
@@ -382,9 +382,9 @@ template <int CALLER> __device__ __forceinline__ Fp2 grp_mul_dense(const Fp2 &a,
 // (a1, a4) of a stored line times (xP, yP): four Fp products on lanes 0..3 of the group
 __device__ __forceinline__ void scale_line(LineRec &l, const Aff<Fp> &P, int sub, int gbase) {
     const int r = sub & 3;
-    const Fp w = r == 0 ? l.a1.c0 : r == 1 ? l.a1.c1 : r == 2 ? l.a4.c0 : l.a4.c1;
+    const Fp w = sel4(r, l.a1.c0, l.a1.c1, l.a4.c0, l.a4.c1);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const Fp q = fp_mul_cols(w, r < 2 ? P.x : P.y);
+    const Fp q = fp_mul_cols(w, sel2(r < 2 ? 0 : 1, P.x, P.y));
 #else
     const Fp q = mul(w, r < 2 ? P.x : P.y);
 #endif
@@ -402,7 +402,7 @@ __device__ __forceinline__ Fp2 grp_mul_line(const Fp2 &f, const LineRec &l, int 
     Fp2 t2 = tmul(f2, l.a1);
     Fp2 t3 = tmul(f3, l.a4);
     Fp2 t2x = mul_xi(t2), t3x = mul_xi(t3);
-    return add(add(t0, w2 ? t2x : t2), w3 ? t3x : t3);
+    return add(add(t0, sel2(w2 ? 0 : 1, t2x, t2)), sel2(w3 ? 0 : 1, t3x, t3));
 }
 // product of the 8 groups of a wave, left in group 0
 // (only the first `live` groups hold something other than one: levels whose partners are all one are skipped)
