@@ -294,7 +294,7 @@ HD bool is_zero(const FpL &a) {                       // exact zero only (the in
     return z == 0;
 }
 // 2P (dbl-2008-s-1); infinity stays infinity because ZZ3 = V * ZZ
-HD Xyzz<FpL> dbl(const Xyzz<FpL> &p) {
+__host__ __device__ __forceinline__ Xyzz<FpL> dbl(const Xyzz<FpL> &p) {
     const FpL U = addL(p.y, p.y);                                 // < 8
     const FpL V = sqrL(U), W = mulL(U, V), S = mulL(p.x, V), XX = sqrL(p.x);     // 64, 16, 16, 64 < 630
     const FpL M = dbl_addL(XX, XX);                               // < 6
@@ -303,7 +303,7 @@ HD Xyzz<FpL> dbl(const Xyzz<FpL> &p) {
     return Xyzz<FpL>{X3, Y3, mulL(V, p.zz), mulL(W, p.zzz)};
 }
 // P + Q (add-2008-s), complete
-HD Xyzz<FpL> add(const Xyzz<FpL> &p, const Xyzz<FpL> &q) {
+__host__ __device__ __forceinline__ Xyzz<FpL> add(const Xyzz<FpL> &p, const Xyzz<FpL> &q) {
     if (is_zero(q.zz)) return p;
     if (is_zero(p.zz)) return q;
     const FpL U1 = mulL(p.x, q.zz), U2 = mulL(q.x, p.zz), S1 = mulL(p.y, q.zzz), S2 = mulL(q.y, p.zzz);   // 16, 16, 8, 8

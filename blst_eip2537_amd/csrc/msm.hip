@@ -696,6 +696,12 @@ template <> __device__ __forceinline__ void store_canon<Fp, FpL>(Xyzz<Fp> *out, 
 // out-of-line complete point operations (fold and one-lane reduce kernels)
 template <class T> static __device__ __noinline__ void xyzz_add_o(Xyzz<T> *r, const Xyzz<T> *a, const Xyzz<T> *b) { *r = add(*a, *b); }
 template <class T> static __device__ __noinline__ void xyzz_dbl_o(Xyzz<T> *r, const Xyzz<T> *a) { *r = dbl(*a); }
+// The one-lane reduce takes the limb-form operations inline: through the out-of-line form every operand
+// travels by pointer, i.e. through scratch memory (848 B per lane, 670 MB written per launch at 2^20).
+template <class T> __device__ __forceinline__ void pt_add(Xyzz<T> &r, const Xyzz<T> &a, const Xyzz<T> &b) { xyzz_add_o<T>(&r, &a, &b); }
+template <class T> __device__ __forceinline__ void pt_dbl(Xyzz<T> &r, const Xyzz<T> &a) { xyzz_dbl_o<T>(&r, &a); }
+__device__ __forceinline__ void pt_add(Xyzz<FpL> &r, const Xyzz<FpL> &a, const Xyzz<FpL> &b) { r = add(a, b); }
+__device__ __forceinline__ void pt_dbl(Xyzz<FpL> &r, const Xyzz<FpL> &a) { r = dbl(a); }
 // 2..8 tasks: one thread per bucket
 template <class F, class T = typename AccumField<F>::T>    // T: the form the accumulate kernel wrote the partials in (G1: FpI or FpL)
 __global__ void __launch_bounds__(256)
@@ -925,7 +931,7 @@ k_msm_reduce8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict
 // select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
 // products are 3x heavier and the 4-lane form wins 2.2 ms to 7.0 ms at 2^16.
 template <class F, class T = typename AccumField<F>::T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 1)      // one wave per SIMD anyway (claim_whole_simd): the whole register file
 k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
               Xyzz<F> *__restrict__ winout) {
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
@@ -945,28 +951,28 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
             const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
             if (t1 > t0) {                                      // multi-task buckets were folded into slot t0
                 Xyzz<T> pt = partial[t0];
-                xyzz_add_o<T>(&R, &R, &pt);
+                pt_add(R, R, pt);
             }
-            xyzz_add_o<T>(&Q, &Q, &R);
+            pt_add(Q, Q, R);
         }
         // sum_{v in (lo, hi]} v * B_v = Q + lo * R
         Xyzz<T> m = xyzz_inf<T>();
         for (int i = 31 - __builtin_clz(lo | 1u); i >= 0; i--) {
-            xyzz_dbl_o<T>(&m, &m);
-            if ((lo >> i) & 1u) xyzz_add_o<T>(&m, &m, &R);
+            pt_dbl(m, m);
+            if ((lo >> i) & 1u) pt_add(m, m, R);
         }
-        xyzz_add_o<T>(&C, &Q, &m);
+        pt_add(C, Q, m);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int off = 32; off >= 1; off >>= 1) {
         Xyzz<T> o = shfl_from(C, (lane + off) & 63);
-        if (lane < off) xyzz_add_o<T>(&C, &C, &o);
+        if (lane < off) pt_add(C, C, o);
     }
     __shared__ Xyzz<T> sm[4];
     if (lane == 0) sm[wave] = C;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++) xyzz_add_o<T>(&C, &C, &sm[k]);
+        for (int k = 1; k < 4; k++) pt_add(C, C, sm[k]);
         store_canon<F, T>(&winout[blockIdx.x], C);
     }
 }
