@@ -375,49 +375,22 @@ static bool device_present() {
     std::lock_guard<std::mutex> lk(g_mu);
     return device_select_locked();
 }
-// Interleaved signed 5-bit windows (Straus): one chain of 260 doublings shared by all records, per
-// record a table of 1..16 multiples and at most 52 additions -- 57 + 22 n microseconds for G1 on the
-// GPU box's host against 100 n for one double-and-add per record, which moves the crossover with the
-// GPU's fixed ~0.4 ms (G2 ~0.75 ms) from 2 records to 16 (G2: 8).
+// Host MSM of the small-call route: msm_interleaved() of curve.h (interleaved signed 5-bit windows, Straus:
+// one chain of 260 doublings shared by all records, per record a table of 1..16 multiples and at most 52
+// additions) -- 57 + 22 n microseconds for G1 on the GPU box's host against 100 n for one double-and-add
+// per record, which moves the crossover with the GPU's fixed ~0.4 ms (G2 ~0.75 ms) from 2 records to 16 (G2: 8).
 template <class F> static int msm_host_small(byte *out, const byte *in, size_t n) {
     const size_t rec = Wire<F>::kMsmRecWords * 4, pb = Wire<F>::kPointWords * 4;
-    constexpr int kW = 5, kWindows = 52, kTable = 1 << (kW - 1);
-    std::vector<Xyzz<F>> table(n * kTable);
-    std::vector<int8_t> digits(n * kWindows);
+    std::vector<Aff<F>> pts(n);
+    std::vector<uint32_t> ks(n * 8);
     for (size_t i = 0; i < n; i++, in += rec) {
-        Aff<F> a;
-        int st = host_decode_point<F>(a, in);
+        int st = host_decode_point<F>(pts[i], in);
         if (st) return st;                                  // first bad record in input order
-        uint32_t sw[8], k[8];
+        uint32_t sw[8];
         memcpy(sw, in + pb, 32);
-        decode_scalar(k, sw);
-        // signed digits in [-15, 16]: k = sum d_w 32^w (the last window takes the final carry)
-        int carry = 0;
-        for (int w = 0; w < kWindows; w++) {
-            const int bit = w * kW, word = bit >> 5, sh = bit & 31;
-            uint32_t v = word < 8 ? k[word] >> sh : 0u;
-            if (sh > 32 - kW && word + 1 < 8) v |= k[word + 1] << (32 - sh);
-            int d = (int)(v & ((1u << kW) - 1u)) + carry;
-            carry = d > kTable;
-            if (carry) d -= 1 << kW;
-            digits[i * kWindows + w] = (int8_t)d;
-        }
-        Xyzz<F> *t = &table[i * kTable];
-        t[0] = from_affine(a);                              // infinity stays infinity in every entry
-        if (kTable > 1) t[1] = dbl(t[0]);
-        for (int m = 2; m < kTable; m++) t[m] = madd(t[m - 1], a);
+        decode_scalar(&ks[i * 8], sw);
     }
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (int w = kWindows - 1; w >= 0; w--) {
-        if (!is_inf(acc))
-            for (int d = 0; d < kW; d++) acc = dbl(acc);
-        for (size_t i = 0; i < n; i++) {
-            const int d = digits[i * kWindows + w];
-            if (d > 0) acc = add(acc, table[i * kTable + d - 1]);
-            else if (d < 0) acc = add(acc, neg(table[i * kTable - d - 1]));
-        }
-    }
-    host_encode_point<F>(out, to_affine(acc));
+    host_encode_point<F>(out, to_affine(msm_interleaved<F>(pts.data(), ks.data(), n)));
     return E_SUCCESS;
 }
 static void pairing_finish(byte *out, const Fp12 &ml);
