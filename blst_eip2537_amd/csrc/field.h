@@ -285,6 +285,71 @@ template <bool REDUCE> HD Fp fp_sqr_cols30_t(const Fp &a) {
     return REDUCE ? fp_reduce_once(r) : r;
 }
 
+// (a b + c d) / 2^384 with ONE reduction: the component of an Fp2 product (u0 v0 - u1 v1, u0 v1 + u1 v0)
+// in 507 multiply-adds instead of two products and an addition (676 + a carry chain).  Inputs in [0, 2p):
+// the sum is below 8 p^2, so the result is below 8 p^2 / R + p = 1.82 p -- inside the lazy range of FpI.
+// Columns 8 .. 16 are carried out after the first 169 products, columns 4 .. 20 after the second; the
+// reduction is the one of fp_mul_cols30_t (its last factor hidden from the optimiser, see above).
+HD Fp fp_mul2_cols30(const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
+    const uint32_t p30[13] = {K_P30};
+    const uint32_t M30 = 0x3fffffffu;
+    uint32_t al[13], bl[13], cl[13], dl[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int bit = 30 * k, i = bit >> 5, s = bit & 31;
+        uint32_t va = a.l[i] >> s, vb = b.l[i] >> s, vc = c.l[i] >> s, vd = d.l[i] >> s;
+        if (s > 2 && i + 1 < 12) {
+            va |= a.l[i + 1] << (32 - s); vb |= b.l[i + 1] << (32 - s);
+            vc |= c.l[i + 1] << (32 - s); vd |= d.l[i + 1] << (32 - s);
+        }
+        al[k] = va & M30; bl[k] = vb & M30; cl[k] = vc & M30; dl[k] = vd & M30;
+        EIP_OPAQUE(al[k]); EIP_OPAQUE(bl[k]); EIP_OPAQUE(cl[k]); EIP_OPAQUE(dl[k]);
+    }
+    uint64_t col[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) col[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)al[j] * bl[i];
+    }
+#pragma unroll
+    for (int k = 8; k <= 16; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)M30; }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)cl[j] * dl[i];
+    }
+#pragma unroll
+    for (int k = 4; k <= 20; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)M30; }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        uint32_t m = ((uint32_t)col[i] * K_N0_30) & (i < 12 ? M30 : 0x00ffffffu);
+        EIP_OPAQUE(m);
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)m * p30[j];
+        if (i < 12) col[i + 1] += col[i] >> 30;
+    }
+    uint32_t dg[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        uint64_t v = col[12 + k] + carry;
+        dg[k] = (uint32_t)v & M30;
+        carry = v >> 30;
+    }
+    dg[14] = 0;
+    dg[15] = 0;
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 24 + 32 * w, q = bit / 30, o = bit % 30;
+        uint64_t t = (uint64_t)dg[q] | ((uint64_t)dg[q + 1] << 30) | ((uint64_t)dg[q + 2] << 60);
+        r.l[w] = (uint32_t)(t >> o);
+    }
+    return r;
+}
+
 // Device Montgomery product.  The operands arrive as canonical 12 x 32-bit limbs and are
 // re-sliced into 14 x 28-bit limbs so that every multiply-add of the schoolbook product and of
 // the reduction is ONE v_mad_u64_u32 accumulating in place into a 64-bit column: 28 terms of
@@ -680,12 +745,21 @@ HD FpI sub(const FpI &a, const FpI &b) {
 }
 HD FpI mul(const FpI &a, const FpI &b) { return FpI{fp_mul_cols_t<false>(a.v, b.v)}; }
 HD FpI sqr(const FpI &a) { return FpI{fp_sqr_cols_t<false>(a.v)}; }
+// a b + c d, reduced once (the radix-2^30 build; two products and an addition otherwise)
+HD FpI mul2(const FpI &a, const FpI &b, const FpI &c, const FpI &d) {
+#if EIP_LIMB_BITS == 30
+    return FpI{fp_mul2_cols30(a.v, b.v, c.v, d.v)};
+#else
+    return add(mul(a, b), mul(c, d));
+#endif
+}
 #else       // the host pass only parses the kernels that use FpI
 HD bool is_zero(const FpI &a) { return is_zero(a.v); }
 HD FpI add(const FpI &a, const FpI &b) { return FpI{add(a.v, b.v)}; }
 HD FpI sub(const FpI &a, const FpI &b) { return FpI{sub(a.v, b.v)}; }
 HD FpI mul(const FpI &a, const FpI &b) { return FpI{fp_mul_host(a.v, b.v)}; }
 HD FpI sqr(const FpI &a) { return FpI{fp_mul_host(a.v, a.v)}; }
+HD FpI mul2(const FpI &a, const FpI &b, const FpI &c, const FpI &d) { return FpI{add(fp_mul_host(a.v, b.v), fp_mul_host(c.v, d.v))}; }
 #endif
 HD bool eq(const FpI &a, const FpI &b) { return is_zero(sub(a, b)); }
 HD FpI neg(const FpI &a) { return sub(FpI{fp_zero()}, a); }

@@ -148,8 +148,8 @@ struct PairProd8 {
         const FpI u = sel4(p, a0, a1, a2, a3), v = sel4(p, b0, b1, b2, b3);     // own components of this pair's operands
         const FpI up = quad_perm<kDppSwap>(u), vp = quad_perm<kDppSwap>(v);         // the partner's
         // q = 0: c0 = u0 v0 - u1 v1      q = 1: c1 = u0 v1 + u1 v0
-        const FpI m1 = mul(sel2(q, u, up), v), m2 = mul(sel2(q, up, u), vp);
-        const FpI c = q ? add(m1, m2) : sub(m1, m2);
+        // one two-product sum with a single reduction (field.h, fp_mul2_cols30); the difference as u1 * (2p - v1)
+        const FpI c = mul2(sel2(q, u, up), v, sel2(q, up, u), sel2(q, neg(vp), vp));
         return Prod4c{group8_pair<0>(c), group8_pair<1>(c), group8_pair<2>(c), group8_pair<3>(c)};
     }
     // an Fp2 predicate holds when it holds on both components

@@ -460,8 +460,9 @@ __device__ __forceinline__ Pair2c prod2c(const FpI &a0, const FpI &b0, const FpI
     // lane r holds component r: (u0, u1) = r ? (other, mine) : (mine, other)
     const FpI u0 = sel2(r, mine_u, other_u), u1 = sel2(r, other_u, mine_u);
     const FpI v0 = sel2(r, mine_v, other_v), v1 = sel2(r, other_v, mine_v);
-    const FpI t0 = mul(u0, v0), t1 = mul(u1, v1), t2 = mul(add(u0, u1), add(v0, v1));
-    const FpI c0 = sub(t0, t1), c1 = sub(sub(t2, t0), t1);
+    // schoolbook with one reduction per component (field.h, fp_mul2_cols30): 2 x 507 multiply-adds and one
+    // negation against Karatsuba's 3 x 338 with two additions and three subtractions
+    const FpI c0 = mul2(u0, v0, u1, neg(v1)), c1 = mul2(u0, v1, u1, v0);
     // keep my component of my product, fetch my component of the partner's product
     const FpI keep = sel2(r, c0, c1), got = quad_perm<kDppSwap>(sel2(r, c1, c0));
     return Pair2c{sel2(r, keep, got), sel2(r, got, keep)};

@@ -37,6 +37,15 @@ int main() {
         if (is_zero_modp(g1, 10) != eq(a, b)) bad++;
         if (!is_zero_modp(subL<8>(A, A), 10) || !is_zero_modp(subL<3>(A, A), 4)) bad++;
     }
+    // the two-product sum with one reduction of the 12 x 32-bit world (field.h, fp_mul2_cols30): operands in [0, 2p)
+    for (int it = 0; it < 300000; it++) {
+        Fp v[4];
+        for (auto &x : v) { for (int k = 0; k < 12; k++) x.l[k] = (uint32_t)rnd(); x.l[11] &= 0x0fffffffu; }      // < 2^380 < 2p
+        if (it % 7 == 0) for (int k = 0; k < 12; k++) v[it % 4].l[k] = k == 11 ? 0x0fffffffu : 0xffffffffu;
+        const Fp got = fp_reduce_once(fp_mul2_cols30(v[0], v[1], v[2], v[3]));
+        const Fp want = add(mul(fp_reduce_once(v[0]), fp_reduce_once(v[1])), mul(fp_reduce_once(v[2]), fp_reduce_once(v[3])));
+        if (!eq(got, want)) bad++;
+    }
     printf("field operations: %ld mismatches\n", bad);
     // extreme limbs: x = all-ones limbs (< 2^384 < 10 p).  With v = x mod p (plain words), mul(v, v) of the R
     // world is x^2 / R; the limb square gives x^2 / R', to_fpi turns that into x^2 R / R'^2, and two products
