@@ -20,3 +20,19 @@ def test_limb_form_matches_host_arithmetic(tmp_path):
     assert out.returncode == 0, out.stdout
     for part in ("field operations", "accumulate chains", "point operations"):
         assert part + ": 0 mismatches" in out.stdout, out.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_pairing_lane_code_matches_host_arithmetic(tmp_path):
+    """csrc/limbk.h + csrc/pairing_limb.h (bounded limb form, RCB projective doubling / addition, Miller walk,
+    membership tests, quad line products, dense products through memory): the lane-group code of the pairing
+    kernels with a group's shares in arrays, against pairing.h / curve.h (tools/pairing_limb_check.hip)."""
+    exe = str(tmp_path / "pairing_limb_check")
+    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "--offload-arch=gfx950", "-Xarch_host", "-mbmi2", "-Xarch_host", "-madx",
+                           "-I" + os.path.join(ROOT, "blst_eip2537_amd", "csrc"), os.path.join(ROOT, "tools", "pairing_limb_check.hip"),
+                           "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    for part in ("helpers", "G1 projective operations", "G1 membership", "Miller walk / G2 membership", "quad line products",
+                 "dense products"):
+        assert part + ": 0 mismatches" in out.stdout, out.stdout
