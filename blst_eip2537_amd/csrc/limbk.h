@@ -21,6 +21,9 @@
 
 namespace eip {
 
+// everything here is inlined into the kernel that uses it (a call would pass limb strings through the stack)
+#define HDF __host__ __device__ __forceinline__
+
 static constexpr int kMaxK = 600;      // 600 p / 2^360 < 2^30
 static constexpr int kMaxSum = 2000;   // any value: top limb below 2^32 with room
 
@@ -37,40 +40,40 @@ constexpr int max4(int a, int b, int c, int d) { return max2(max2(a, b), max2(c,
 
 #define EIP_EACH_LANE _Pragma("unroll") for (int i = 0; i < N; i++)
 
-template <int K2, int K, int N> HD LV<K2, N> widen(const LV<K, N> &a) {
+template <int K2, int K, int N> HDF LV<K2, N> widen(const LV<K, N> &a) {
     static_assert(K2 >= K, "widen() cannot shrink a bound");
     LV<K2, N> r;
     EIP_EACH_LANE r.l[i] = a.l[i];
     return r;
 }
-template <int A, int B, int N> HD LV<A + B, N> addB(const LV<A, N> &a, const LV<B, N> &b) {
+template <int A, int B, int N> HDF LV<A + B, N> addB(const LV<A, N> &a, const LV<B, N> &b) {
     LV<A + B, N> r;
     EIP_EACH_LANE r.l[i] = addL(a.l[i], b.l[i]);
     return r;
 }
 // a - b as a + B p - b
-template <int A, int B, int N> HD LV<A + B, N> subB(const LV<A, N> &a, const LV<B, N> &b) {
+template <int A, int B, int N> HDF LV<A + B, N> subB(const LV<A, N> &a, const LV<B, N> &b) {
     LV<A + B, N> r;
     EIP_EACH_LANE r.l[i] = subL<B>(a.l[i], b.l[i]);
     return r;
 }
-template <int B, int N> HD LV<B, N> negB(const LV<B, N> &b) {
+template <int B, int N> HDF LV<B, N> negB(const LV<B, N> &b) {
     LV<B, N> r;
     EIP_EACH_LANE r.l[i] = negL<B>(b.l[i]);
     return r;
 }
-template <int A, int N> HD LV<2 * A, N> dblB(const LV<A, N> &a) {
+template <int A, int N> HDF LV<2 * A, N> dblB(const LV<A, N> &a) {
     LV<2 * A, N> r;
     EIP_EACH_LANE r.l[i] = addL(a.l[i], a.l[i]);
     return r;
 }
-template <int A, int N> HD LV<3 * A, N> mul3B(const LV<A, N> &a) {
+template <int A, int N> HDF LV<3 * A, N> mul3B(const LV<A, N> &a) {
     LV<3 * A, N> r;
     EIP_EACH_LANE r.l[i] = dbl_addL(a.l[i], a.l[i]);
     return r;
 }
 // a * 2^S: a shift of the limb string, no carries (the two parts of a limb do not overlap)
-template <int S> HD FpL shlL(const FpL &a) {
+template <int S> HDF FpL shlL(const FpL &a) {
     static_assert(S >= 1 && S <= 4, "");
     FpL r;
 #pragma unroll
@@ -78,7 +81,7 @@ template <int S> HD FpL shlL(const FpL &a) {
     r.l[12] = (a.l[12] << S) | (a.l[11] >> (30 - S));
     return r;
 }
-template <int S, int A, int N> HD LV<(A << S), N> shlB(const LV<A, N> &a) {
+template <int S, int A, int N> HDF LV<(A << S), N> shlB(const LV<A, N> &a) {
     LV<(A << S), N> r;
     EIP_EACH_LANE r.l[i] = shlL<S>(a.l[i]);
     return r;
@@ -87,7 +90,7 @@ template <int S, int A, int N> HD LV<(A << S), N> shlB(const LV<A, N> &a) {
 // (the value / 2^360, below 2^30) and ph = floor(p / 2^360) + 1, q = floor(t M / 2^52) with M = floor(2^52 / ph)
 // never exceeds t / ph, so q p <= value, and it is short of value / p by less than 2: the rest is below 3 p.
 // One multiplication for q, then value - q p in one signed carry pass (q p30[k] < 2^40).
-HD FpL weak_reduceL(const FpL &a) {
+HDF FpL weak_reduceL(const FpL &a) {
     const uint32_t p30[13] = {K_P30};
     constexpr uint64_t ph = (uint64_t)0x001a0111u + 1u;
     constexpr uint32_t M = (uint32_t)((1ull << 52) / ph);
@@ -103,19 +106,19 @@ HD FpL weak_reduceL(const FpL &a) {
     r.l[12] = (uint32_t)((int64_t)a.l[12] - (int64_t)((uint64_t)q * p30[12]) + c);
     return r;
 }
-template <int A, int N> HD LV<3, N> weak_reduceB(const LV<A, N> &a) {
+template <int A, int N> HDF LV<3, N> weak_reduceB(const LV<A, N> &a) {
     static_assert(A <= kMaxK, "weak reduction needs a top limb below 2^30");
     LV<3, N> r;
     EIP_EACH_LANE r.l[i] = weak_reduceL(a.l[i]);
     return r;
 }
-template <int A, int B, int N> HD LV<prod_bound((long)A * B), N> mulB(const LV<A, N> &a, const LV<B, N> &b) {
+template <int A, int B, int N> HDF LV<prod_bound((long)A * B), N> mulB(const LV<A, N> &a, const LV<B, N> &b) {
     static_assert(A <= kMaxK && B <= kMaxK, "product operand too large");
     LV<prod_bound((long)A * B), N> r;
     EIP_EACH_LANE r.l[i] = mulL(a.l[i], b.l[i]);
     return r;
 }
-template <int A, int N> HD LV<prod_bound((long)A * A), N> sqrB(const LV<A, N> &a) {
+template <int A, int N> HDF LV<prod_bound((long)A * A), N> sqrB(const LV<A, N> &a) {
     static_assert(A <= kMaxK, "product operand too large");
     LV<prod_bound((long)A * A), N> r;
     EIP_EACH_LANE r.l[i] = sqrL(a.l[i]);
@@ -123,34 +126,34 @@ template <int A, int N> HD LV<prod_bound((long)A * A), N> sqrB(const LV<A, N> &a
 }
 // a b + c d with one reduction
 template <int A, int B, int C, int D, int N>
-HD LV<prod_bound((long)A * B + (long)C * D), N> mul2B(const LV<A, N> &a, const LV<B, N> &b, const LV<C, N> &c, const LV<D, N> &d) {
+HDF LV<prod_bound((long)A * B + (long)C * D), N> mul2B(const LV<A, N> &a, const LV<B, N> &b, const LV<C, N> &c, const LV<D, N> &d) {
     static_assert(A <= kMaxK && B <= kMaxK && C <= kMaxK && D <= kMaxK, "product operand too large");
     LV<prod_bound((long)A * B + (long)C * D), N> r;
     EIP_EACH_LANE r.l[i] = mul2L(a.l[i], b.l[i], c.l[i], d.l[i]);
     return r;
 }
 // value == 0 mod p, per lane
-template <int K, int N> HD LanePred<N> is_zero_modpB(const LV<K, N> &a) {
+template <int K, int N> HDF LanePred<N> is_zero_modpB(const LV<K, N> &a) {
     LanePred<N> r;
     EIP_EACH_LANE r.b[i] = is_zero_modp(a.l[i], (uint32_t)K + 1u);
     return r;
 }
-template <int N> HD LanePred<N> operator&(const LanePred<N> &a, const LanePred<N> &b) {
+template <int N> HDF LanePred<N> operator&(const LanePred<N> &a, const LanePred<N> &b) {
     LanePred<N> r;
     EIP_EACH_LANE r.b[i] = a.b[i] && b.b[i];
     return r;
 }
-template <int N> HD LanePred<N> operator|(const LanePred<N> &a, const LanePred<N> &b) {
+template <int N> HDF LanePred<N> operator|(const LanePred<N> &a, const LanePred<N> &b) {
     LanePred<N> r;
     EIP_EACH_LANE r.b[i] = a.b[i] || b.b[i];
     return r;
 }
-template <int N> HD LanePred<N> operator!(const LanePred<N> &a) {
+template <int N> HDF LanePred<N> operator!(const LanePred<N> &a) {
     LanePred<N> r;
     EIP_EACH_LANE r.b[i] = !a.b[i];
     return r;
 }
-template <int K, int N> HD LV<K, N> lv_const(const FpL &c) {
+template <int K, int N> HDF LV<K, N> lv_const(const FpL &c) {
     LV<K, N> r;
     EIP_EACH_LANE r.l[i] = c;
     return r;
@@ -245,7 +248,7 @@ template <int K0, int K1, int K2, int K3, int N> struct Prod4 { LV<K0, N> r0; LV
 // bounds are large and alike on the b side.
 constexpr int pb2(int a, int b, int bm) { return prod_bound((long)a * (b + bm)); }
 template <class X, int A0, int A1, int A2, int A3, int B0, int B1, int B2, int B3, int N>
-HD Prod4<pb2(A0, B0, max4(B0, B1, B2, B3)), pb2(A1, B1, max4(B0, B1, B2, B3)), pb2(A2, B2, max4(B0, B1, B2, B3)), pb2(A3, B3, max4(B0, B1, B2, B3)), N>
+HDF Prod4<pb2(A0, B0, max4(B0, B1, B2, B3)), pb2(A1, B1, max4(B0, B1, B2, B3)), pb2(A2, B2, max4(B0, B1, B2, B3)), pb2(A3, B3, max4(B0, B1, B2, B3)), N>
 round4_fp2(const X &x, const LV<A0, N> &a0, const LV<A1, N> &a1, const LV<A2, N> &a2, const LV<A3, N> &a3,
            const LV<B0, N> &b0, const LV<B1, N> &b1, const LV<B2, N> &b2, const LV<B3, N> &b3) {
     static_assert(max4(A0, A1, A2, A3) <= kMaxK && max4(B0, B1, B2, B3) <= kMaxK, "product operand too large");
@@ -262,14 +265,14 @@ round4_fp2(const X &x, const LV<A0, N> &a0, const LV<A1, N> &a1, const LV<A2, N>
     return r;
 }
 // (1 + u) a on component-split lanes: component 0 = a0 - a1, component 1 = a0 + a1
-template <class X, int A, int N> HD LV<2 * A, N> mul_xiB(const X &x, const LV<A, N> &a) {
+template <class X, int A, int N> HDF LV<2 * A, N> mul_xiB(const X &x, const LV<A, N> &a) {
     const auto ap = x.swap(a);
     return addB(a, x.pick_q(negB(ap), ap));
 }
 
 // Whole Fp values replicated on 4 lanes: lane r multiplies (a_r, b_r), every lane gets all four results.
 template <class X, int A0, int A1, int A2, int A3, int B0, int B1, int B2, int B3, int N>
-HD Prod4<prod_bound((long)A0 * B0), prod_bound((long)A1 * B1), prod_bound((long)A2 * B2), prod_bound((long)A3 * B3), N>
+HDF Prod4<prod_bound((long)A0 * B0), prod_bound((long)A1 * B1), prod_bound((long)A2 * B2), prod_bound((long)A3 * B3), N>
 round4_fp(const X &x, const LV<A0, N> &a0, const LV<A1, N> &a1, const LV<A2, N> &a2, const LV<A3, N> &a3,
           const LV<B0, N> &b0, const LV<B1, N> &b1, const LV<B2, N> &b2, const LV<B3, N> &b3) {
     static_assert(max4(A0, A1, A2, A3) <= kMaxK && max4(B0, B1, B2, B3) <= kMaxK, "product operand too large");

@@ -21,35 +21,35 @@ namespace eip {
 // ---- how a group of lanes multiplies ---------------------------------------------------------------------
 struct PolFp2c {        // Fp2 values split by component over 4 lane pairs (line walk)
     template <class X, class A0, class A1, class A2, class A3, class B0, class B1, class B2, class B3>
-    static HD auto round(const X &x, const A0 &a0, const A1 &a1, const A2 &a2, const A3 &a3, const B0 &b0, const B1 &b1,
+    static HDF auto round(const X &x, const A0 &a0, const A1 &a1, const A2 &a2, const A3 &a3, const B0 &b0, const B1 &b1,
                          const B2 &b2, const B3 &b3) {
         return round4_fp2(x, a0, a1, a2, a3, b0, b1, b2, b3);
     }
-    template <class X, class A> static HD auto twist(const X &x, const A &a) { return mul_xiB(x, a); }      // b / 4 = 1 + u
+    template <class X, class A> static HDF auto twist(const X &x, const A &a) { return mul_xiB(x, a); }      // b / 4 = 1 + u
 };
 struct PolFp4 {         // whole Fp values replicated on 4 lanes (G1 membership)
     template <class X, class A0, class A1, class A2, class A3, class B0, class B1, class B2, class B3>
-    static HD auto round(const X &x, const A0 &a0, const A1 &a1, const A2 &a2, const A3 &a3, const B0 &b0, const B1 &b1,
+    static HDF auto round(const X &x, const A0 &a0, const A1 &a1, const A2 &a2, const A3 &a3, const B0 &b0, const B1 &b1,
                          const B2 &b2, const B3 &b3) {
         return round4_fp(x, a0, a1, a2, a3, b0, b1, b2, b3);
     }
-    template <class X, class A> static HD A twist(const X &, const A &a) { return a; }                     // b / 4 = 1
+    template <class X, class A> static HDF A twist(const X &, const A &a) { return a; }                     // b / 4 = 1
 };
 
 template <class A, class B, class C, class D, class E> struct Out5 { A x; B y; C z; D l0; E l1; };
-template <class A, class B, class C, class D, class E> HD Out5<A, B, C, D, E> out5(const A &a, const B &b, const C &c, const D &d, const E &e) {
+template <class A, class B, class C, class D, class E> HDF Out5<A, B, C, D, E> out5(const A &a, const B &b, const C &c, const D &d, const E &e) {
     return Out5<A, B, C, D, E>{a, b, c, d, e};
 }
 template <class A, class B, class C, class D, class E, class F> struct Out6 { A x; B y; C z; D l0; E l1; F l2; };
 template <class A, class B, class C, class D, class E, class F>
-HD Out6<A, B, C, D, E, F> out6(const A &a, const B &b, const C &c, const D &d, const E &e, const F &f) {
+HDF Out6<A, B, C, D, E, F> out6(const A &a, const B &b, const C &c, const D &d, const E &e, const F &f) {
     return Out6<A, B, C, D, E, F>{a, b, c, d, e, f};
 }
 
 // 2 (X : Y : Z), two rounds.  Also returns what the tangent line at the point needs:
 //   l0 = Y^2 - 3 b Z^2,  l1 = Y Z      (line: l0 + (-3 X^2) xP v + (2 Y Z) yP v w; X^2 is left to the product tree)
 template <class Pol, class X, int KX, int KY, int KZ, int N>
-HD auto proj_dbl(const X &x, const LV<KX, N> &px, const LV<KY, N> &py, const LV<KZ, N> &pz) {
+HDF auto proj_dbl(const X &x, const LV<KX, N> &px, const LV<KY, N> &py, const LV<KZ, N> &pz) {
     const auto r1 = Pol::round(x, px, py, pz, pz, py, py, pz, py);             // X Y, Y^2, Z^2, Z Y
     const auto E = shlB<2>(mul3B(Pol::twist(x, r1.r2)));                       // 3 b Z^2 = 12 (twist) Z^2
     const auto t0 = subB(r1.r1, mul3B(E));                                     // Y^2 - 9 b Z^2
@@ -68,7 +68,7 @@ template <int N> struct WalkPt { LV<WalkK::X, N> x; LV<WalkK::Y, N> y; LV<WalkK:
 template <int N> struct LineRecD { LV<LineK::A0, N> a0; LV<LineK::A1D, N> a1; LV<LineK::A4D, N> a4; };
 template <int N> struct LineRecA { LV<LineK::A0, N> a0; LV<LineK::A1A, N> a1; LV<LineK::A4A, N> a4; };
 
-template <class X, int N> HD LineRecD<N> miller_dbl_l(const X &x, WalkPt<N> &T) {
+template <class X, int N> HDF LineRecD<N> miller_dbl_l(const X &x, WalkPt<N> &T) {
     const auto o = proj_dbl<PolFp2c>(x, T.x, T.y, T.z);
     LineRecD<N> l{widen<LineK::A0>(o.l0), T.x, widen<LineK::A4D>(o.l1)};
     T = WalkPt<N>{widen<WalkK::X>(o.x), widen<WalkK::Y>(o.y), widen<WalkK::Z>(o.z)};
@@ -78,7 +78,7 @@ template <class X, int N> HD LineRecD<N> miller_dbl_l(const X &x, WalkPt<N> &T) 
 // use the same (-3 xP, 2 yP) factors as for a tangent:  6 (theta xQ - lambda yQ) + (2 theta)(-3 xP) v + (3 lambda)(2 yP) v w
 // with theta = Y - yQ Z, lambda = X - xQ Z.  Not complete (T = +-Q gives Z = 0 from then on, which the
 // membership test reads as "not in G2" -- such Q are not in G2).
-template <class X, int N> HD LineRecA<N> miller_add_l(const X &x, WalkPt<N> &T, const LV<1, N> &qx, const LV<1, N> &qy) {
+template <class X, int N> HDF LineRecA<N> miller_add_l(const X &x, WalkPt<N> &T, const LV<1, N> &qx, const LV<1, N> &qy) {
     const auto r1 = PolFp2c::round(x, qy, qx, qy, qx, T.z, T.z, T.z, T.z);
     const auto theta = subB(T.y, r1.r0);
     const auto lambda = subB(T.x, r1.r1);
@@ -92,7 +92,7 @@ template <class X, int N> HD LineRecA<N> miller_add_l(const X &x, WalkPt<N> &T, 
 }
 // After the walk T = [|z|] Q.  Q in G2  <=>  psi(Q) == [z] Q = -T:   psi(Q).x Z == X,  psi(Q).y Z == -Y,  Z != 0
 // (blst_p2_affine_in_g2, reference src/eip2537.c:1051).  Per lane: true when Q is NOT a member.
-template <class X, int N> HD LanePred<N> g2_not_member_l(const X &x, const WalkPt<N> &T, const LV<1, N> &qx, const LV<1, N> &qy) {
+template <class X, int N> HDF LanePred<N> g2_not_member_l(const X &x, const WalkPt<N> &T, const LV<1, N> &qx, const LV<1, N> &qy) {
     const auto cx = x.pick_q(qx, negB(qx)), cy = x.pick_q(qy, negB(qy));                    // conjugates: component 1 negated
     const auto kx = x.pick_q(lv_const<1, N>(FpL{{K_PSI_X_C0_R390_30}}), lv_const<1, N>(FpL{{K_PSI_X_C1_R390_30}}));
     const auto ky = x.pick_q(lv_const<1, N>(FpL{{K_PSI_Y_C0_R390_30}}), lv_const<1, N>(FpL{{K_PSI_Y_C1_R390_30}}));
@@ -107,7 +107,7 @@ template <class X, int N> HD LanePred<N> g2_not_member_l(const X &x, const WalkP
 struct G1K { static constexpr int X = 8, Y = 16, Z = 8; };
 template <int N> struct G1Pt { LV<G1K::X, N> x; LV<G1K::Y, N> y; LV<G1K::Z, N> z; };
 // P1 + P2, complete (RCB algorithm 7, a = 0, 3 b = 12), three rounds of four products
-template <class X, int N> HD G1Pt<N> proj_add_g1(const X &x, const G1Pt<N> &a, const G1Pt<N> &b) {
+template <class X, int N> HDF G1Pt<N> proj_add_g1(const X &x, const G1Pt<N> &a, const G1Pt<N> &b) {
     const auto r1 = round4_fp(x, a.x, a.y, a.z, addB(a.x, a.y), b.x, b.y, b.z, addB(b.x, b.y));         // t0, t1, t2, (X1 + Y1)(X2 + Y2)
     const auto t3 = subB(subB(r1.r3, r1.r0), r1.r1);                                                     // X1 Y2 + X2 Y1
     const auto t2b = shlB<2>(mul3B(r1.r2));                                                              // 3 b Z1 Z2
@@ -121,9 +121,10 @@ template <class X, int N> HD G1Pt<N> proj_add_g1(const X &x, const G1Pt<N> &a, c
     const auto r3 = round4_fp(x, t4, t1p, t0p, t4, y3p, z3, y3p, z3);                                    // t4 y3', t1' z3, t0' y3', t4 z3
     return G1Pt<N>{widen<G1K::X>(subB(r2.r2, r3.r0)), widen<G1K::Y>(addB(r3.r2, r3.r1)), widen<G1K::Z>(addB(r3.r3, r2.r3))};
 }
-template <class X, int N> HD G1Pt<N> g1_mul_zabs_l(const X &x, const G1Pt<N> &base) {
+template <class X, int N> HDF G1Pt<N> g1_mul_zabs_l(const X &x, const G1Pt<N> &base) {
     const uint64_t z = K_Z_ABS;
     G1Pt<N> acc = base;
+#pragma unroll 1
     for (int i = 62; i >= 0; i--) {
         const auto d = proj_dbl<PolFp4>(x, acc.x, acc.y, acc.z);
         acc = G1Pt<N>{widen<G1K::X>(d.x), widen<G1K::Y>(d.y), widen<G1K::Z>(d.z)};
@@ -133,7 +134,7 @@ template <class X, int N> HD G1Pt<N> g1_mul_zabs_l(const X &x, const G1Pt<N> &ba
 }
 // phi(P) == -[z^2] P with phi(x, y) = (beta x, y)  (blst_p1_affine_in_g1, reference src/eip2537.c:1041).
 // P affine, not infinity, canonical limbs.  Per lane: true when P is NOT a member.
-template <class X, int N> HD LanePred<N> g1_not_member_l(const X &x, const LV<1, N> &xp, const LV<1, N> &yp) {
+template <class X, int N> HDF LanePred<N> g1_not_member_l(const X &x, const LV<1, N> &xp, const LV<1, N> &yp) {
     const G1Pt<N> P{widen<G1K::X>(xp), widen<G1K::Y>(yp), lv_const<G1K::Z, N>(fpl_one())};
     const G1Pt<N> T = g1_mul_zabs_l(x, g1_mul_zabs_l(x, P));
     const auto beta = lv_const<1, N>(FpL{{K_BETA_R390_30}});
@@ -157,7 +158,7 @@ template <int N> struct Fp12Q { LV<TreeK::F, N> own[3]; };
 
 // scaled line (a1 = X^2 xs or (2 theta) xs, a4 = (l1) ys) from a stored record; xs = -3 xP, ys = 2 yP (Fp: the same on every lane)
 template <bool ADD, class X, int K1, int N>
-HD auto line_scale_a1(const X &x, const LV<K1, N> &r1, const LV<1, N> &xs) {
+HDF auto line_scale_a1(const X &x, const LV<K1, N> &r1, const LV<1, N> &xs) {
     if constexpr (ADD) {
         return mulB(r1, xs);
     } else {
@@ -168,7 +169,7 @@ HD auto line_scale_a1(const X &x, const LV<K1, N> &r1, const LV<1, N> &xs) {
 }
 // f <- f * line.  a0 / a1 / a4: this lane's component of the line's coefficients (a1, a4 already scaled).
 template <class X, int K0, int K1, int K4, int N>
-HD void quad_fold_line(const X &x, Fp12Q<N> &f, const LV<K0, N> &a0, const LV<K1, N> &a1, const LV<K4, N> &a4) {
+HDF void quad_fold_line(const X &x, Fp12Q<N> &f, const LV<K0, N> &a0, const LV<K1, N> &a1, const LV<K4, N> &a4) {
     // operand forms (A = own component, B = q ? partner : -partner) of a0, a1, xi a1, a4, xi a4
     const auto a0p = x.swap(a0);
     const auto a0B = x.pick_q(negB(a0p), a0p);
@@ -206,7 +207,7 @@ HD void quad_fold_line(const X &x, Fp12Q<N> &f, const LV<K0, N> &a0, const LV<K1
 }
 // f = the line itself (first line of a quad): slots w^0, w^2, w^3
 template <class X, int K0, int K1, int K4, int N>
-HD Fp12Q<N> quad_seed_line(const X &x, const LV<K0, N> &a0, const LV<K1, N> &a1, const LV<K4, N> &a4) {
+HDF Fp12Q<N> quad_seed_line(const X &x, const LV<K0, N> &a0, const LV<K1, N> &a1, const LV<K4, N> &a4) {
     const auto z = lv_const<TreeK::F, N>(fpl_zero());
     Fp12Q<N> f;
     f.own[0] = x.pick_c(widen<TreeK::F>(a0), widen<TreeK::F>(a4));       // c = 0: f0 = a0      c = 1: f3 = a4
@@ -218,21 +219,21 @@ HD Fp12Q<N> quad_seed_line(const X &x, const LV<K0, N> &a0, const LV<K1, N> &a1,
 // ---- dense products through shared memory --------------------------------------------------------------------
 // An Fp12 element in memory: 12 limb strings [k][q] (coefficient of w^k, component q), kElemStride dwords each.
 static constexpr int kLimbStride = 14, kElemWords = 12 * kLimbStride;
-HD FpL elem_load(const uint32_t *e, int k, int q) {
+HDF FpL elem_load(const uint32_t *e, int k, int q) {
     FpL v;
     const uint32_t *s = e + (k * 2 + q) * kLimbStride;
 #pragma unroll
     for (int i = 0; i < 13; i++) v.l[i] = s[i];
     return v;
 }
-HD void elem_store(uint32_t *e, int k, int q, const FpL &v) {
+HDF void elem_store(uint32_t *e, int k, int q, const FpL &v) {
     uint32_t *d = e + (k * 2 + q) * kLimbStride;
 #pragma unroll
     for (int i = 0; i < 13; i++) d[i] = v.l[i];
 }
 // UPL consecutive terms j0 .. j0 + UPL - 1 of component q of coefficient k of f * g  (operands at most 3 p):
 //   sum_j (f_j * g_{k-j} * (xi if j > k)).q        each term one two-product sum
-template <int UPL> HD LV<2 * UPL + 1, 1> dense_terms(const uint32_t *f, const uint32_t *g, int k, int q, int j0) {
+template <int UPL> HDF LV<2 * UPL + 1, 1> dense_terms(const uint32_t *f, const uint32_t *g, int k, int q, int j0) {
     using V = LV<3, 1>;
     LV<2 * UPL + 1, 1> acc;
 #pragma unroll
