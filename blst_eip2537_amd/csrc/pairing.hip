@@ -284,7 +284,7 @@ k_pair_lines8(const PairQL *__restrict__ ql, const uint8_t *__restrict__ flagP, 
 __device__ __forceinline__ int tower_slot(int k) { return (k & 1) * 3 + (k >> 1); }       // [c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2] = [w^0 w^2 w^4 w^1 w^3 w^5]
 
 static constexpr int kTreeQuads = 64;                              // quads per block (256 threads)
-static constexpr int kScratchLimbStrings = 192;                    // partial sums of a dense level (at most 8 products x 12 x 2)
+static constexpr int kScratchLimbStrings = 256;                    // partial sums of a dense pass: (256 / LP) products x 12 outputs x PARTS <= 252
 struct TreeShared {
     uint32_t elems[kTreeQuads * kElemWords];
     uint32_t scratch[kScratchLimbStrings * kLimbStride];
@@ -292,6 +292,7 @@ struct TreeShared {
 // one level of the pairwise product: element 2 i * stride *= element (2 i + 1) * stride, i < nprod
 template <int UPL> __device__ __forceinline__ void dense_level(TreeShared &sh, int stride, int nprod, int tid) {
     constexpr int LP = 72 / UPL, PARTS = 6 / UPL, PER_PASS = 256 / LP;
+    static_assert(UPL == 6 || PER_PASS * 12 * PARTS <= kScratchLimbStrings, "scratch too small");
     const int slot = tid / LP, idx = tid % LP, o = idx / PARTS, part = idx % PARTS;
     for (int p0 = 0; p0 < nprod; p0 += PER_PASS) {                 // uniform
         const int pr = p0 + slot;
