@@ -40,6 +40,9 @@ constexpr int max4(int a, int b, int c, int d) { return max2(max2(a, b), max2(c,
 
 #define EIP_EACH_LANE _Pragma("unroll") for (int i = 0; i < N; i++)
 
+// selection BY VALUE: "c ? a.l[i] : b.l[i]" on lvalues selects an address and pins both values in scratch memory
+HDF uint32_t pickv(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+
 template <int K2, int K, int N> HDF LV<K2, N> widen(const LV<K, N> &a) {
     static_assert(K2 >= K, "widen() cannot shrink a bound");
     LV<K2, N> r;

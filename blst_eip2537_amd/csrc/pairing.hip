@@ -380,7 +380,7 @@ k_pair_fold(const LineL *__restrict__ lines, const PairPL *__restrict__ pl, uint
         const auto sq = mulB(x.pick_q(addB(r1, rp), dblB(r1)), x.pick_q(subB(r1, rp), rp));
         LV<max2(decltype(sq)::kK, LineK::A1A), 1> pre;
 #pragma unroll
-        for (int t = 0; t < 13; t++) pre.l[0].l[t] = is_add ? r1.l[0].l[t] : sq.l[0].l[t];
+        for (int t = 0; t < 13; t++) pre.l[0].l[t] = pick2(is_add, r1.l[0].l[t], sq.l[0].l[t]);      // by value: an lvalue conditional would pin both in scratch
         const auto a1 = mulB(pre, xs), a4 = mulB(r4, ys);
         if (!have) { f = quad_seed_line(x, a0, a1, a4); have = true; }
         else quad_fold_line(x, f, a0, a1, a4);
@@ -467,7 +467,7 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     }
     // blocks per step: as many as keep the whole grid (blocks x 68 steps) in ONE round of 2 blocks per CU (512
     // slots); one block more than that and the kernel takes two block-times
-    const uint32_t max_blocks_per_step = 512u / kSteps;                         // 7
+    const uint32_t max_blocks_per_step = (256u * EIP_FOLD_WAVES) / kSteps;     // 7
     const uint32_t tree_blocks = (uint32_t)std::min<size_t>(max_blocks_per_step, (k + kTreeQuads - 1) / kTreeQuads);
     PairBufs b{};
     int st = pairing_reserve(e, k, 64, (size_t)kSteps * tree_blocks * kElemWords * 4 + (size_t)kSteps * sizeof(Fp12), b);

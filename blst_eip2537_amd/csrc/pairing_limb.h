@@ -168,39 +168,34 @@ HDF auto line_scale_a1(const X &x, const LV<K1, N> &r1, const LV<1, N> &xs) {
     }
 }
 // f <- f * line.  a0 / a1 / a4: this lane's component of the line's coefficients (a1, a4 already scaled).
+// Term-major: the three products by a0 first, then those by a1 / xi a1, then a4 / xi a4, so that only one
+// coefficient's operand forms (A = own component, B = q ? partner : -partner) are alive at a time.
+template <class X, int KL, int N> struct QuadOperand { LV<KL, N> A, B; };
+template <class X, int KL, int N> HDF QuadOperand<X, KL, N> quad_operand(const X &x, const LV<KL, N> &l) {
+    const auto lp = x.swap(l);
+    return QuadOperand<X, KL, N>{l, x.pick_q(negB(lp), lp)};
+}
 template <class X, int K0, int K1, int K4, int N>
 HDF void quad_fold_line(const X &x, Fp12Q<N> &f, const LV<K0, N> &a0, const LV<K1, N> &a1, const LV<K4, N> &a4) {
-    // operand forms (A = own component, B = q ? partner : -partner) of a0, a1, xi a1, a4, xi a4
-    const auto a0p = x.swap(a0);
-    const auto a0B = x.pick_q(negB(a0p), a0p);
-    const auto a1p = x.swap(a1);
-    const auto a1B = x.pick_q(negB(a1p), a1p);
-    const auto xa1 = addB(a1, a1B);                       // component q of (1 + u) a1:  a1.0 - a1.1  |  a1.1 + a1.0
-    const auto xa1p = x.swap(xa1);
-    const auto xa1B = x.pick_q(negB(xa1p), xa1p);
-    const auto a4p = x.swap(a4);
-    const auto a4B = x.pick_q(negB(a4p), a4p);
-    const auto xa4 = addB(a4, a4B);
-    const auto xa4p = x.swap(xa4);
-    const auto xa4B = x.pick_q(negB(xa4p), xa4p);
     constexpr int K1X = 2 * K1, K4X = 2 * K4;
-    const auto a1w = widen<K1X>(a1), a1Bw = widen<K1X>(a1B);
-    const auto a4w = widen<K4X>(a4), a4Bw = widen<K4X>(a4B);
-    // per output t: which form of a1 / a4 this half uses
-    const auto A1_0 = x.pick_c(xa1, a1w), B1_0 = x.pick_c(xa1B, a1Bw);
-    const auto A1_2 = x.pick_c(a1w, xa1), B1_2 = x.pick_c(a1Bw, xa1B);
-    const auto A4_01 = x.pick_c(xa4, a4w), B4_01 = x.pick_c(xa4B, a4Bw);
-    const auto A4_2 = x.pick_c(a4w, xa4), B4_2 = x.pick_c(a4Bw, xa4B);
-    // both components of own[] (the own half's) and of the other half's registers
-    const auto s00 = x.template same_c<0>(f.own[0]), s01 = x.template same_c<1>(f.own[0]);
-    const auto s10 = x.template same_c<0>(f.own[1]), s11 = x.template same_c<1>(f.own[1]);
-    const auto s20 = x.template same_c<0>(f.own[2]), s21 = x.template same_c<1>(f.own[2]);
-    const auto n0 = addB(addB(mul2B(s00, a0, s01, a0B), mul2B(s20, A1_0, s21, B1_0)),
-                         mul2B(x.template other_c<0>(f.own[0]), A4_01, x.template other_c<1>(f.own[0]), B4_01));
-    const auto n1 = addB(addB(mul2B(s10, a0, s11, a0B), mul2B(s00, a1w, s01, a1Bw)),
-                         mul2B(x.template other_c<0>(f.own[1]), A4_01, x.template other_c<1>(f.own[1]), B4_01));
-    const auto n2 = addB(addB(mul2B(s20, a0, s21, a0B), mul2B(s10, A1_2, s11, B1_2)),
-                         mul2B(x.template other_c<0>(f.own[2]), A4_2, x.template other_c<1>(f.own[2]), B4_2));
+    // own[t] a0
+    const auto o0 = quad_operand(x, a0);
+    const auto p0 = mul2B(x.template same_c<0>(f.own[0]), o0.A, x.template same_c<1>(f.own[0]), o0.B);
+    const auto p1 = mul2B(x.template same_c<0>(f.own[1]), o0.A, x.template same_c<1>(f.own[1]), o0.B);
+    const auto p2 = mul2B(x.template same_c<0>(f.own[2]), o0.A, x.template same_c<1>(f.own[2]), o0.B);
+    // own[t - 1] A1[t]:   c = 0: (xi a1, a1, a1)    c = 1: (a1, a1, xi a1)
+    const auto o1 = quad_operand(x, widen<K1X>(a1));
+    const auto o1x = quad_operand(x, addB(a1, x.pick_q(negB(x.swap(a1)), x.swap(a1))));      // component q of (1 + u) a1
+    const auto q1 = addB(p1, mul2B(x.template same_c<0>(f.own[0]), o1.A, x.template same_c<1>(f.own[0]), o1.B));
+    const auto q0 = addB(p0, mul2B(x.template same_c<0>(f.own[2]), x.pick_c(o1x.A, o1.A), x.template same_c<1>(f.own[2]), x.pick_c(o1x.B, o1.B)));
+    const auto q2 = addB(p2, mul2B(x.template same_c<0>(f.own[1]), x.pick_c(o1.A, o1x.A), x.template same_c<1>(f.own[1]), x.pick_c(o1.B, o1x.B)));
+    // other[t] A4[t]:     c = 0: (xi a4, xi a4, a4)    c = 1: (a4, a4, xi a4)
+    const auto o4 = quad_operand(x, widen<K4X>(a4));
+    const auto o4x = quad_operand(x, addB(a4, x.pick_q(negB(x.swap(a4)), x.swap(a4))));
+    const auto A01 = x.pick_c(o4x.A, o4.A), B01 = x.pick_c(o4x.B, o4.B);
+    const auto n0 = addB(q0, mul2B(x.template other_c<0>(f.own[0]), A01, x.template other_c<1>(f.own[0]), B01));
+    const auto n1 = addB(q1, mul2B(x.template other_c<0>(f.own[1]), A01, x.template other_c<1>(f.own[1]), B01));
+    const auto n2 = addB(q2, mul2B(x.template other_c<0>(f.own[2]), x.pick_c(o4.A, o4x.A), x.template other_c<1>(f.own[2]), x.pick_c(o4.B, o4x.B)));
     f.own[0] = widen<TreeK::F>(n0);
     f.own[1] = widen<TreeK::F>(n1);
     f.own[2] = widen<TreeK::F>(n2);
@@ -244,10 +239,15 @@ template <int UPL> HDF LV<2 * UPL + 1, 1> dense_terms(const uint32_t *f, const u
         // G = g_kk or (1 + u) g_kk = (g0 - g1, g0 + g1);   A = G.q,  B = q ? G.0 : -G.1
         const auto d = subB(g0, g1);
         const auto s = addB(g0, g1);                                            // <= 6
-        const auto G0 = wrap ? d : widen<6>(g0);
-        const auto G1 = wrap ? s : widen<6>(g1);
-        const auto A = q ? G1 : G0;
-        const auto B = q ? G0 : negB(G1);
+        // selections by value, limb by limb (an lvalue conditional on whole values selects an ADDRESS and pins both in scratch)
+        const auto nG1w = negB(s), nG1 = negB(widen<6>(g1));
+        LV<6, 1> A, B;
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const uint32_t G0 = pickv(wrap, d.l[0].l[i], g0.l[0].l[i]), G1 = pickv(wrap, s.l[0].l[i], g1.l[0].l[i]);
+            A.l[0].l[i] = pickv(q != 0, G1, G0);
+            B.l[0].l[i] = pickv(q != 0, G0, pickv(wrap, nG1w.l[0].l[i], nG1.l[0].l[i]));
+        }
         const auto t = mul2B(f0, A, f1, B);                                     // 2 * 3 * 6 / 630 + 2 = 2
         static_assert(decltype(t)::kK == 2, "");
         if (u == 0) acc.l[0] = t.l[0];
