@@ -1016,6 +1016,88 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     }
 }
 
+// ---- two-level bucket reduce (G1, c = 16 plans) -------------------------------------------------------
+// The one-lane reduce above is a latency chain: 2 S additions, an offset multiple of ~24 operations and a
+// 9-level block tree in a row on 56 K lanes, 0.9 ms for ~9 % of the MSM's field products.  Here the
+// weights are split instead: bucket value v = 256 hi + lo + 1, so
+//     sum_v v B_v  =  256 sum_hi hi Row_hi  +  sum_lo (lo + 1) Col_lo,      Row_hi = sum_lo B,   Col_lo = sum_hi B
+// and the row and column sums are PLAIN sums of the 2^15 buckets of a window (the same two additions per
+// bucket as the running sums, but independent): k_msm_rowcol runs them as strided per-lane chains of
+// kRcChain buckets plus a short wavefront tree, like the accumulate.  What is left per window are weighted
+// sums over 128 + 256 entries: k_msm_reduce_rc, the 4-lane running-sum kernel of the small plans on 32 blocks.
+// The host's Horner takes R_w = sum hi Row_hi and C_w = sum (lo + 1) Col_lo as two 8-bit half-windows.
+static constexpr uint32_t kRcCols = 256, kRcChain = 16;
+__host__ __device__ inline uint32_t rc_rows(const MsmPlan &pl, int w) { return (w == pl.W - 1 ? pl.BT : pl.B) / kRcCols; }
+__host__ __device__ inline uint32_t rc_base(const MsmPlan &pl, int w) { return (uint32_t)w * (pl.B / kRcCols + kRcCols); }   // entries before window w
+__global__ void __launch_bounds__(256)
+k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, Xyzz<FpL> *__restrict__ rc) {
+    const Xyzz<FpL> *__restrict__ partial = reinterpret_cast<const Xyzz<FpL> *>(partial_);
+    const uint32_t lanes_w = 2u * pl.B / kRcChain;                     // lanes of a signed window: rows + columns
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const int w = (int)min(t / lanes_w, (uint32_t)(pl.W - 1));
+    const uint32_t local = t - (uint32_t)w * lanes_w, nr = rc_rows(pl, w);
+    if (local >= 2u * nr * kRcCols / kRcChain) return;                 // whole waves
+    const uint32_t row_lanes = nr * (kRcCols / kRcChain);
+    const bool is_row = local < row_lanes;                             // uniform in the wave
+    const uint32_t lj = is_row ? kRcCols / kRcChain : nr / kRcChain;  // lanes per job
+    const uint32_t l2 = is_row ? local : local - row_lanes, job = l2 / lj, sub = l2 % lj;
+    // row job: buckets 256 job + (sub + i lj);   column job: buckets 256 (sub + i lj) + job
+    const uint32_t first = (uint32_t)w * pl.B + (is_row ? job * kRcCols + sub : sub * kRcCols + job);
+    const uint32_t step = is_row ? lj : lj * kRcCols;
+    // the next bucket's sum is loaded while the current addition runs (one wave per SIMD: nothing else hides the two
+    // dependent loads, taskoff then the 208-byte point)
+    auto fetch = [&](uint32_t i, Xyzz<FpL> &pt) {
+        const uint32_t g = first + i * step;
+        const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+        if (t1 > t0) pt = partial[t0];                                  // multi-task buckets were folded into slot t0
+        else pt = xyzz_inf<FpL>();
+    };
+    Xyzz<FpL> acc, nxt;
+    fetch(0, acc);
+    fetch(1, nxt);
+#pragma unroll 1
+    for (uint32_t i = 1; i < kRcChain; i++) {
+        const Xyzz<FpL> cur = nxt;
+        if (i + 1 < kRcChain) fetch(i + 1, nxt);                        // in flight during the addition below
+        acc = add(acc, cur);
+    }
+    const int lane = threadIdx.x & 63;
+    for (uint32_t off = lj >> 1; off >= 1; off >>= 1) {                 // lj <= 32: the job's lanes are one aligned run of the wave
+        const Xyzz<FpL> o = shfl_from(acc, (lane + (int)off) & 63);
+        if (sub < off) acc = add(acc, o);
+    }
+    if (sub == 0) rc[rc_base(pl, w) + (is_row ? job : nr + job)] = acc;
+}
+// grid = 2 W blocks: block 2 w sums hi Row_hi (weights from 0), block 2 w + 1 sums (lo + 1) Col_lo; 64 four-lane
+// groups per block, each a run of S entries:  sum_{e in [a, b)} (e + fw) X_e = Q + a R  with the running sums
+// taken from the top, Q skipping its last addition when the weights start at 0.
+__global__ void __launch_bounds__(256, 1)
+k_msm_reduce_rc(const Xyzz<FpL> *__restrict__ rc, MsmPlan pl, Xyzz<Fp> *__restrict__ winout) {
+    const int w = blockIdx.x >> 1, kind = blockIdx.x & 1;
+    claim_whole_simd();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
+    const uint32_t nr = rc_rows(pl, w), n = kind ? kRcCols : nr, fw = kind ? 1u : 0u;
+    const Xyzz<FpL> *ent = rc + rc_base(pl, w) + (kind ? nr : 0u);
+    const uint32_t S = n / 64u, a = (uint32_t)(threadIdx.x >> 2) * S;   // 64 groups
+    Xyzz<FpL> R = xyzz_inf<FpL>(), Q = xyzz_inf<FpL>();
+    for (uint32_t e = a + S; e > a; e--) {
+        R = add4(R, ent[e - 1], r, gb);
+        if (e - 1 > a || fw) Q = add4(Q, R, r, gb);
+    }
+    Xyzz<FpL> C = add4(Q, small_mul4(R, a, r, gb), r, gb);
+    for (int off = 4; off < 64; off <<= 1) {
+        Xyzz<FpL> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 4) C = add4(C, o, r, gb);
+    }
+    __shared__ Xyzz<FpL> sm[4];
+    if (lane == 0) sm[wave] = C;
+    __syncthreads();
+    if (wave == 0 && lane < 4) {
+        for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
+        if (lane == 0) store_canon<Fp, FpL>(&winout[blockIdx.x], C);
+    }
+}
+
 static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const PtL *ptl, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
     if (chain_bound && ptl)
@@ -1062,6 +1144,11 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const 
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
+static void launch_rowcol(hipStream_t s, uint32_t blocks, const Xyzz<Fp> *partial, const uint32_t *taskoff, const MsmPlan &pl, Xyzz<FpL> *rc, Xyzz<Fp> *winout) {
+    hipLaunchKernelGGL(k_msm_rowcol, dim3(blocks), dim3(256), 0, s, partial, taskoff, pl, rc);
+    hipLaunchKernelGGL(k_msm_reduce_rc, dim3(2u * (uint32_t)pl.W), dim3(256), 0, s, rc, pl, winout);
+}
+static void launch_rowcol(hipStream_t, uint32_t, const Xyzz<Fp2> *, const uint32_t *, const MsmPlan &, Xyzz<FpL> *, Xyzz<Fp2> *) {}
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; static constexpr const char *kName = "eip::Fp"; };
@@ -1117,12 +1204,20 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         red_blocks = (uint32_t)(pl.W - 1) * rg.bn + rg.bt;
         if (red_blocks <= 256u || env_rb || pl.S >= 4096u) break;
     }
-    const size_t nwin_out = red_blocks;
-
     // G1 plans run accumulate, fold and reduce in limb form (limb30.h): the decode kernel writes 168-byte
     // limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernels.
     static const bool env_limb = [] { const char *v = getenv("EIP2537_LIMB_FORM"); return !v || atoi(v) != 0; }();
     const bool limb_form = !ReduceCfg<F>::kFourLane && env_limb && (pl.c > 13 ? !four : four);     // G1: (one lane, reduce1) or (two lanes, reduce4)
+    // G1, c = 16: the two-level reduce (row / column sums, then 2 W small weighted sums); EIP2537_REDUCE_RC=0: the one-lane chain
+    // Measured at 2^20 (profiles/r03_two_level_reduce.txt): row / column sums 0.60 ms + weighted sums 0.24 ms against 0.89 ms
+    // for the one-lane chain -- no gain, because 17 half-window units of buckets (the unsigned top window counts twice)
+    // make 1 088 waves of 16-bucket chains for 1 024 SIMDs, and the 64 SIMDs that get two waves set the time (with the
+    // last unit dropped: 0.37 ms, 3.43 instead of 3.80 ms per MSM).  Off by default; EIP2537_REDUCE_RC=1 selects it.
+    static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return v && atoi(v) != 0; }();
+    const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B % (kRcCols * 64u) == 0 && pl.BT % (kRcCols * 64u) == 0;
+    if (two_level) red_blocks = 2u * (uint32_t)pl.W;
+    const size_t nwin_out = red_blocks;
+    const size_t rc_bytes = two_level ? (size_t)(rc_base(pl, pl.W - 1) + rc_rows(pl, pl.W - 1) + kRcCols) * sizeof(Xyzz<FpL>) : 0;
     HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
@@ -1130,7 +1225,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
     HIPCHK(e->digits.reserve((size_t)pl.W * n * 4));                               // digits [W][n]
     HIPCHK(e->hist16.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
-    HIPCHK(e->slice_base.reserve((size_t)pl.W * nslices * nbmax * 4));                // base   [W][slices][nbmax]
+    HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * nslices * nbmax * 4, rc_bytes)));   // base [W][slices][nbmax]; after the scatter: the row / column sums
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
@@ -1199,7 +1294,13 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipEventRecord(e->ev_b, s));
     launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
     launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
-    launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
+    if (two_level) {
+        auto *rc = reinterpret_cast<Xyzz<FpL> *>(e->slice_base.p);
+        const uint32_t rc_lanes = (uint32_t)(pl.W - 1) * (2u * pl.B / kRcChain) + 2u * pl.BT / kRcChain;
+        static const uint32_t env_cut = [] { const char *v = getenv("EIP2537_RC_CUT"); return v ? (uint32_t)atoi(v) : 0u; }();   // timing experiment: drop blocks (wrong result)
+        launch_rowcol(s, (rc_lanes + 255u) / 256u - env_cut, partial, taskoff, pl, rc, winout);
+    } else
+        launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
@@ -1215,6 +1316,14 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
 
     // Horner over windows on the host (W * c doublings + a handful of additions)
     Xyzz<F> acc = xyzz_inf<F>();
+    if (two_level) {
+        // window sum = 256 R_w + C_w: two half-windows of 8 bits each
+        for (int w = pl.W - 1; w >= 0; w--)
+            for (int h = 0; h < 2; h++) {
+                for (int d = 0; d < pl.c / 2; d++) acc = dbl(acc);
+                acc = add(acc, hw[2 * w + h]);
+            }
+    } else
     for (int w = pl.W - 1; w >= 0; w--) {
         for (int d = 0; d < pl.c; d++) acc = dbl(acc);
         const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
