@@ -23,6 +23,7 @@
 #include "codec.h"
 #include "pairing.h"
 #include "h2c.h"
+#include "limbk.h"
 #include "engine.h"
 #include "../../include/eip2537.h"
 #include "../../include/eip2537_hip.h"
@@ -328,12 +329,18 @@ static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_in
     if (!e) return E_MEMORY_ERROR;
     const void *d_in = in;
     if (!device_input) {
-        int st = stage_input(e, in, n * Wire<F>::kMsmRecWords * 4);
-        if (st) return st;
+        // the device pipeline stages the buffer itself, chunk by chunk, with the decode of a chunk behind its copy (msm.hip)
+        if (e->input.reserve(n * Wire<F>::kMsmRecWords * 4) != hipSuccess) {
+            fprintf(stderr, "[eip2537_hip] hipMalloc of %zu staging bytes failed\n", n * (size_t)Wire<F>::kMsmRecWords * 4);
+            e->failed = true;
+            return E_MEMORY_ERROR;
+        }
+        e->host_src = in;
         d_in = e->input.p;
     }
     Xyzz<F> acc;
     int st = msm_dispatch<F>(e, d_in, n, reinterpret_cast<uint32_t *>(&acc));
+    e->host_src = nullptr;                      // never retained past the call (an early error return leaves it set)
     if (st) return st;
     if (want_partial) {
         memcpy(out, &acc, sizeof acc);
@@ -1018,6 +1025,81 @@ API int eip2537_hip_field_selftest(uint64_t seed, size_t n, uint64_t mismatches[
     (void)hipFree(d_bad);
     if (!ok) return E_MEMORY_ERROR;
     for (int k = 0; k < 4; k++) mismatches[k] = h_bad[k];
+    return 0;
+}
+
+// Device self-test of the LIMB-FORM primitives (limb30.h, limbk.h, fp_mul2_cols30): the G1 accumulate / fold /
+// reduce and every pairing kernel compute on them, and tools/limb30_check.hip / pairing_limb_check.hip run the same
+// source on the HOST only -- the 13 x 30-bit column product has a record of device-only code generation trouble
+// (field.h).  Everything is checked against the independent 12 x 32-bit CIOS product, on the device, with operands
+// grown to the bounds the kernels use (8 p, 10 p, 25 p, 600 p) and the 24-bit top limb that to_limbs() produces.
+//   [0] mulL  [1] sqrL  [2] mul2L on grown operands  [3] fp_mul2_cols30  [4] to_limbs / to_fpi round trip
+//   [5] weak_reduceL / shlL  [6] subL / sub2L / addL / dbl_addL / negL  [7] is_zero_modp
+__device__ static FpL selftest_grow(const FpL &a, uint32_t k) {           // a + k p
+    uint32_t p1[13];
+    kp30<1>(p1);
+    FpL pl, r = a;
+    for (int i = 0; i < 13; i++) pl.l[i] = p1[i];
+    for (uint32_t e = 0; e < k; e++) r = addL(r, pl);
+    return r;
+}
+__global__ void k_limb_selftest(uint64_t seed, unsigned n, unsigned long long *bad) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = (seed ^ (0x9E3779B97F4A7C15ull * (i + 1))) | 1;
+    // canonical Montgomery values (factor 2^384) from arbitrary operands
+    const Fp one_m{{K_ONE}}, r390{{K_R390_MODP}};
+    const Fp a = fp_mul_limbs32(selftest_operand(s, i), one_m), b = fp_mul_limbs32(selftest_operand(s, i + 3), one_m);
+    const Fp c = fp_mul_limbs32(selftest_operand(s, i + 5), one_m), d = fp_mul_limbs32(selftest_operand(s, i + 6), one_m);
+    auto lift = [&](const Fp &v) { return to_limbs(fp_mul_limbs32(v, r390)); };                    // v R -> v R' (top limb: 24 bits)
+    auto canon_of = [&](const FpL &v) { return fp_reduce_once(to_fpi(v).v); };                     // v R' (< 600 p) -> v R canonical
+    auto mul32 = [&](const Fp &x, const Fp &y) { return fp_mul_limbs32(x, y); };
+    const FpL A = lift(a), B = lift(b), C = lift(c), D = lift(d);
+    const uint32_t grow[4] = {0u, 7u, 9u, 24u};
+    const FpL Ag = selftest_grow(A, grow[i & 3]), Bg = selftest_grow(B, grow[(i >> 2) & 3]);
+    if (!eq(canon_of(mulL(Ag, Bg)), mul32(a, b))) atomicAdd(&bad[0], 1ull);
+    if (!eq(canon_of(sqrL(Ag)), mul32(a, a))) atomicAdd(&bad[1], 1ull);
+    {
+        const FpL g1 = subL<8>(A, B), g2 = subL<6>(B, A);                        // bounds 9 x 7, plus a second product: < 630
+        const Fp want = sub(mul32(sub(a, b), sub(b, a)), mul32(a, b));
+        if (!eq(canon_of(mul2L(g1, g2, A, negL<2>(B))), want)) atomicAdd(&bad[2], 1ull);
+        const FpL big = selftest_grow(C, 590u);                                  // the largest operands limbk.h admits
+        if (!eq(canon_of(mulL(big, D)), mul32(c, d))) atomicAdd(&bad[2], 1ull);
+    }
+    if (!eq(fp_reduce_once(fp_mul2_cols30(a, b, c, d)), add(mul32(a, b), mul32(c, d)))) atomicAdd(&bad[3], 1ull);
+    if (!eq(canon_of(A), a) || !eq(from_limbs(to_limbs(a)), a)) atomicAdd(&bad[4], 1ull);
+    {
+        const FpL big = selftest_grow(A, 100u + (i % 490u));
+        const FpL w = weak_reduceL(big);
+        const FpL room = negL<3>(w);                                             // 3 p - w must not be negative
+        if (!eq(canon_of(w), a) || (int32_t)room.l[12] < 0) atomicAdd(&bad[5], 1ull);
+        if (!eq(canon_of(shlL<3>(Ag)), dbl(dbl(dbl(a)))) || !eq(canon_of(shlL<1>(Ag)), dbl(a))) atomicAdd(&bad[5], 1ull);
+    }
+    if (!eq(canon_of(subL<2>(A, B)), sub(a, b)) || !eq(canon_of(sub2L<4>(A, B)), sub(a, dbl(b))) || !eq(canon_of(addL(Ag, Bg)), add(a, b)) ||
+        !eq(canon_of(dbl_addL(A, B)), add(dbl(a), b)) || !eq(canon_of(negL<2>(B)), neg(b)))
+        atomicAdd(&bad[6], 1ull);
+    if (is_zero_modp(subL<8>(A, B), 10) != eq(a, b) || !is_zero_modp(subL<8>(A, A), 10) || !is_zero_modp(selftest_grow(subL<3>(A, A), 20u), 25))
+        atomicAdd(&bad[7], 1ull);
+}
+API int eip2537_hip_limb_selftest(uint64_t seed, size_t n, uint64_t mismatches[8]) {
+    if (!mismatches || n == 0 || n > (1u << 24)) return E_INVALID_LENGTH;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!device_select_locked()) return E_MEMORY_ERROR;
+    }
+    DeviceGuard guard(g_pools[g_split[0]].ordinal);
+    if (!guard.ok) return E_MEMORY_ERROR;
+    unsigned long long *d_bad = nullptr;
+    if (hipMalloc(&d_bad, 8 * sizeof(unsigned long long)) != hipSuccess) return E_MEMORY_ERROR;
+    unsigned long long h_bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = hipMemset(d_bad, 0, sizeof(h_bad)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_limb_selftest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, seed, (unsigned)n, d_bad);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_bad);
+    if (!ok) return E_MEMORY_ERROR;
+    for (int k = 0; k < 8; k++) mismatches[k] = h_bad[k];
     return 0;
 }
 

@@ -34,6 +34,7 @@ struct Engine {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr;
     // staging + per-call workspace (grow-only)
     DevBuf input;          // H2D copy of a host caller's records
+    const void *host_src = nullptr;   // set by a host-input MSM call: the pipeline stages `input` from here itself, in chunks (msm.hip)
     DevBuf misc;           // first-error word, scan totals, split-bucket counters
     // MSM
     DevBuf pts;            // decoded affine points, AoS

@@ -181,8 +181,9 @@ __device__ __forceinline__ int decode_point_limbs(PtL *dst, const uint32_t *w, b
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts, PtL *__restrict__ ptl,
-             uint32_t *__restrict__ digits, unsigned long long *err) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+             uint32_t *__restrict__ digits, unsigned long long *err, uint32_t rec0, uint32_t rec1) {
+    const uint32_t i = rec0 + blockIdx.x * 256u + threadIdx.x;       // records [rec0, rec1): a host input arrives in chunks
+    if (i >= rec1) return;
     bool live = false;
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < pl.n) {
@@ -283,9 +284,9 @@ static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit cou
 
 __global__ void __launch_bounds__(1024)
 k_msm_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-           uint32_t *__restrict__ hist16) {
+           uint32_t *__restrict__ hist16, uint32_t slice0) {
     __shared__ uint32_t h[kLdsWords];
-    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    const uint32_t slice = slice0 + blockIdx.x, w = blockIdx.y;
     const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
     const uint32_t words = (nbw + 1u) / 2u;
     for (uint32_t t = threadIdx.x; t < words; t += 1024u) h[t] = 0;
@@ -1270,8 +1271,33 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     HIPCHK(hipEventRecord(e->ev_start, s));
     PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
-    hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, ptl, digits, err);
-    hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);
+    // Measured (profiles/r03_h2d_chunks.txt, 2^20 records, same box): 1 chunk 7.31 ms, 4 chunks 7.51, 8 chunks 7.65, 16 chunks
+    // 8.08 -- every pageable hipMemcpyAsync pays its own staging set-up and the decode + histogram it would hide are only
+    // 0.2 ms, so the default stays ONE copy followed by the kernels; EIP2537_H2D_CHUNKS=n selects the chunked form.
+    static const uint32_t env_chunks = [] { const char *v = getenv("EIP2537_H2D_CHUNKS"); return v ? (uint32_t)atoi(v) : 1u; }();
+    if (e->host_src && nslices >= 8 && env_chunks > 1) {
+        // Host input (the reference ABI): the copy is the longest single step of the call (168 MB at ~53 GB/s = 3.2 of
+        // 7.3 ms at 2^20), and decode + slice histograms need only the records that have arrived -- the histograms are
+        // per 32 768-record slice anyway.  The buffer is staged in chunks of whole slices on the engine's stream and
+        // every chunk's decode and histogram launches follow it, so they run while the host thread is busy with the
+        // next chunk's pageable copy.  The caller's buffer is not touched after the last chunk's copy has returned.
+        const uint32_t nchunks = std::min<uint32_t>(env_chunks, nslices / 2u);
+        const size_t rec_bytes = (size_t)Wire<F>::kMsmRecWords * 4;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t sl0 = (uint32_t)((uint64_t)nslices * c / nchunks), sl1 = (uint32_t)((uint64_t)nslices * (c + 1) / nchunks);
+            const uint32_t r0 = sl0 * kSlice, r1 = (uint32_t)std::min<size_t>((size_t)sl1 * kSlice, n);
+            HIPCHK(hipMemcpyAsync(static_cast<char *>(e->input.p) + (size_t)r0 * rec_bytes, static_cast<const char *>(e->host_src) + (size_t)r0 * rec_bytes,
+                                  (size_t)(r1 - r0) * rec_bytes, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_msm_decode<F>, dim3((r1 - r0 + 255u) / 256u), dim3(256), 0, s, in, pl, pts, ptl, digits, err, r0, r1);
+            hipLaunchKernelGGL(k_msm_hist, dim3(sl1 - sl0, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, sl0);
+        }
+    } else {
+        if (e->host_src)
+            HIPCHK(hipMemcpyAsync(e->input.p, e->host_src, n * (size_t)Wire<F>::kMsmRecWords * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, ptl, digits, err, 0u, (uint32_t)n);
+        hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
+    }
+    e->host_src = nullptr;
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
@@ -1491,7 +1517,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     }
     HIPCHK(hipEventRecord(e->ev_start, s));
     hipLaunchKernelGGL(k_msm_decode_batch<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, real, (uint32_t)n, d_coff, M, pts, digits, err);
-    hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16);
+    hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;
     HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));

@@ -96,6 +96,8 @@ def lib():
     L.eip2537_hip_set_window.argtypes = [ctypes.c_int]
     L.eip2537_hip_field_selftest.restype = ctypes.c_int
     L.eip2537_hip_field_selftest.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+    L.eip2537_hip_limb_selftest.restype = ctypes.c_int
+    L.eip2537_hip_limb_selftest.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
     L.eip2537_hip_device_count.restype = ctypes.c_int
     L.eip2537_hip_device_count.argtypes = []
     L.eip2537_hip_trim.restype = ctypes.c_size_t
@@ -254,6 +256,16 @@ class Eip2537Executor:
         operand pairs against the independent 12 x 32-bit product (eip2537_hip.h)."""
         bad = (ctypes.c_uint64 * 4)()
         rc = lib().eip2537_hip_field_selftest(seed, n, bad)
+        if rc != 0:
+            raise Eip2537Error(rc)
+        return tuple(bad)
+
+    @staticmethod
+    def limb_selftest(seed, n):
+        """Mismatch counts of the limb-form device primitives (eip2537_hip.h: mulL, sqrL, mul2L, fp_mul2_cols30, limb
+        conversion, weak reduction / shifts, sums and differences, zero test) against the 12 x 32-bit product."""
+        bad = (ctypes.c_uint64 * 8)()
+        rc = lib().eip2537_hip_limb_selftest(seed, n, bad)
         if rc != 0:
             raise Eip2537Error(rc)
         return tuple(bad)

@@ -98,6 +98,11 @@ int eip2537_hip_set_window(int c);
  * pseudo-random and extreme operand pairs against an independent 12 x 32-bit product, all on the device.
  * mismatches[0..3] = product, square, lazy product, lazy square.  Returns 0 when the test ran. */
 int eip2537_hip_field_selftest(uint64_t seed, size_t n, uint64_t mismatches[4]);
+/* The same for the limb-form primitives the G1 MSM and every pairing kernel compute on (13 limbs of 30 bits, Montgomery
+ * factor 2^390: products, squares, two-product sums with one reduction, weak reduction, linear steps, zero test), with
+ * operands grown to the bounds the kernels use.  mismatches[0..7] = mulL, sqrL, mul2L, fp_mul2_cols30, limb conversion,
+ * weak_reduceL / shlL, sums and differences, is_zero_modp. */
+int eip2537_hip_limb_selftest(uint64_t seed, size_t n, uint64_t mismatches[8]);
 
 #ifdef __cplusplus
 }

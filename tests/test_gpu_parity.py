@@ -233,3 +233,11 @@ def test_device_field_products_selftest(X):
     recorded in field.h (the host build of the same source was correct, the device build was not)."""
     for seed in (1, 0x2537):
         assert X.field_selftest(seed, 1 << 18) == (0, 0, 0, 0)
+
+
+def test_device_limb_form_selftest(X):
+    """The limb-form primitives of the G1 MSM and the pairing kernels (13 x 30-bit limbs, Montgomery factor 2^390:
+    mulL, sqrL, mul2L, fp_mul2_cols30, conversions, weak reduction, linear steps, zero test) on the DEVICE against the
+    12 x 32-bit product, with operands grown to the kernels' bounds -- the host tools run the same source on the host only."""
+    for seed in (1, 0x2537):
+        assert X.limb_selftest(seed, 1 << 17) == (0,) * 8
