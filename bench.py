@@ -24,7 +24,9 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   cpu_baseline   the CPU oracle's restatement of the reference path (Bos-Coster, 1 thread) on the
                  same records, on this box's host cores; cpu_all_cores: a bucket-method MSM on all
                  host cores, for context, NOT the reference's algorithm
-  secondary      the second half of BASELINE's metric: one 2^12-pair bls12_pairing check
+  secondary      the second half of BASELINE's metric: one 2^12-pair bls12_pairing check, with its own roofline
+                 (HBM fraction + PMC traffic of the line walk), roofline_valu (walk, G1 membership, line products) and cpu_baseline
+  strong         (N > 1) BASELINE config 5 literally: ONE 2^20-record MSM and ONE 2^12-pair check sharded over the N GPUs
   in_library_split  (N > 1) bls12_g1multiexp on a host buffer, cut over the N devices inside the library
 """
 import argparse
@@ -85,6 +87,50 @@ def golden(workload, log2n):
         with open(p) as f:
             return bytes.fromhex(f.read().strip())
     return None
+
+
+# multiply-adds the pairing kernels execute per pair (csrc/pairing_limb.h): a round is one two-product sum with a single
+# reduction (507) per lane of the 8-lane walk, one product (338) per lane of the 4-lane G1 membership chain; a folded line
+# costs a quad of lanes 9 two-product sums + 3 products each, once per Miller step
+PAIR_MADS = {
+    "k_pair_lines8": (63 * 2 + 5 * 4 + 2) * 507 * 8,          # 63 doublings x 2 rounds, 5 additions x 4, membership 2
+    "k_pair_check_g1": (126 * 2 + 10 * 3 + 2) * 338 * 4,      # two 63-doubling chains x 2 rounds, 10 additions x 3, final 2
+    "k_pair_fold": 68 * 4 * (9 * 507 + 3 * 338),             # 68 lines per pair
+}
+
+
+def pairing_valu(k, walk_ms, check_ms, fold_ms, pipeline_ms):
+    """Executed v_mad_u64_u32 lane-ops of the three pairing kernels against the measured issue roof."""
+    def leg(name, ms):
+        mads = PAIR_MADS[name] * k
+        return {"kernel": name, "ms": ms, "lane_mads": mads, "achieved": mads / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                "frac": mads / (ms * 1e-3) / MAD_PEAK if ms > 0 else None}
+    total = sum(PAIR_MADS.values()) * k
+    return {"bound": "valu (v_mad_u64_u32 issue)", "peak": MAD_PEAK / 1e12, "unit": "T mad lane-ops/s",
+            "kernels": [leg("k_pair_lines8", walk_ms), leg("k_pair_check_g1", check_ms), leg("k_pair_fold", fold_ms)],
+            "device_pipeline": {"lane_mads": total, "ms": pipeline_ms, "frac": total / (pipeline_ms * 1e-3) / MAD_PEAK if pipeline_ms > 0 else None},
+            "note": "executed multiply-adds per pair x pairs / kernel time from HIP events on the engine's streams (membership runs on a second "
+                    "stream beside the walk; k_pair_fold's interval includes k_pair_tree2); peak = chip-wide v_mad_u64_u32 rate measured by "
+                    "tools/valu_probe.hip (profiles/r01_valu_probe.txt)"}
+
+
+def traffic_for(wl, log2n, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this same command
+    (profiles/rNN_traffic.json, newest first; counters cannot be read from inside the process)."""
+    for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath):
+            continue
+        with open(tpath) as f:
+            tj = json.load(f)
+        for ent in (tj if isinstance(tj, list) else [tj]):
+            if ent.get("workload") == wl and ent.get("log2n") == log2n and ent.get("kernel") == kernel:
+                note = ("PMC (FETCH_SIZE+WRITE_SIZE)*1024 per launch, raw; %.3g with the gfx950 x2 FETCH correction (calibrated for coalesced "
+                        "streams only). Source: profiles/%s" % (ent["traffic_bytes_fetch_x2"], ent.get("source", tname)))
+                if ent.get("note"):
+                    note += "; " + ent["note"]
+                return ent["traffic_bytes_raw"], note
+    return None, None
 
 
 def stats_ms(samples):
@@ -254,62 +300,76 @@ def main():
     start = rank * n_local
     log2_total = log2n if args.scaling == "strong" else log2n + (world.bit_length() - 1)
 
-    host = make_records(X, wl, n_local, start, log2_total)
-    if wl == "pairing" and rank == world - 1:
-        host = pairing_fixup(X, host, n_total)
-    d_in = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
-    torch.cuda.synchronize()
-
-    gather_buf = None
-    psz = {"g1msm": 192, "g2msm": 384, "pairing": 576}[wl]
-    if world > 1:
-        gather_buf = torch.empty(world * psz, dtype=torch.uint8, device="cuda")
-
-    kernel_ms, pipe_ms, step_ms = [], [], []
-
-    def step():
-        t0 = time.perf_counter()
-        if world == 1:
-            out = X.dev_call(FULL[wl], d_in.data_ptr(), n_local)
-        else:
-            part = X.dev_call(PART[wl], d_in.data_ptr(), n_local)
-            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gather_buf, mine.cuda())
-                allp = bytes(gather_buf.cpu().numpy().tobytes())
-            else:
-                parts = [torch.empty_like(mine) for _ in range(world)]
-                dist.all_gather(parts, mine)
-                allp = b"".join(bytes(t.numpy().tobytes()) for t in parts)
-            out = X.combine(COMB[wl], [allp[i * psz:(i + 1) * psz] for i in range(world)])
-        step_ms.append((time.perf_counter() - t0) * 1e3)
-        p, k = X.last_timing()
-        pipe_ms.append(p)
-        kernel_ms.append(k)
-        return out
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = None
-    for _ in range(args.warmup):
-        out = step()
-    kernel_ms.clear()
-    pipe_ms.clear()
-    step_ms.clear()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    plan = X.last_plan() or {}
+    def timed_leg(lwl, ln_local, ln_total, lstart, llog2_total, steps, warmup):
+        """W warm-up + K timed steps of one workload, sharded by contiguous record range over the ranks: every rank reduces
+        its shard to one partial, the partials cross the ranks in ONE all_gather (RCCL) and every rank combines them.  The
+        partial leaves the library on the host (the window Horner / the 63-squaring Horner are host code), so a step is:
+        pinned host -> device copy, all_gather_into_tensor, one device -> host copy, one stream synchronisation."""
+        lhost = make_records(X, lwl, ln_local, lstart, llog2_total)
+        if lwl == "pairing" and rank == world - 1:
+            lhost = pairing_fixup(X, lhost, ln_total)
+        d_buf = torch.frombuffer(bytearray(lhost), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        lpsz = {"g1msm": 192, "g2msm": 384, "pairing": 576}[lwl]
+        pin_in = pin_out = dev_in = gbuf = None
+        if world > 1 and backend == "nccl":
+            pin_in = torch.empty(lpsz, dtype=torch.uint8).pin_memory()
+            pin_out = torch.empty(world * lpsz, dtype=torch.uint8).pin_memory()
+            dev_in = torch.empty(lpsz, dtype=torch.uint8, device="cuda")
+            gbuf = torch.empty(world * lpsz, dtype=torch.uint8, device="cuda")
+        k_ms, p_ms, s_ms, aux = [], [], [], []
+
+        def one():
+            t0 = time.perf_counter()
+            if world == 1:
+                o = X.dev_call(FULL[lwl], d_buf.data_ptr(), ln_local)
+            else:
+                part = X.dev_call(PART[lwl], d_buf.data_ptr(), ln_local)
+                if backend == "nccl":
+                    pin_in.copy_(torch.frombuffer(bytearray(part), dtype=torch.uint8))
+                    dev_in.copy_(pin_in, non_blocking=True)
+                    dist.all_gather_into_tensor(gbuf, dev_in)
+                    pin_out.copy_(gbuf, non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                    allp = bytes(pin_out.numpy().tobytes())
+                else:
+                    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+                    parts = [torch.empty_like(mine) for _ in range(world)]
+                    dist.all_gather(parts, mine)
+                    allp = b"".join(bytes(t.numpy().tobytes()) for t in parts)
+                o = X.combine(COMB[lwl], [allp[i * lpsz:(i + 1) * lpsz] for i in range(world)])
+            s_ms.append((time.perf_counter() - t0) * 1e3)
+            pm, km = X.last_timing()
+            p_ms.append(pm)
+            k_ms.append(km)
+            aux.append(X.last_timing_aux())
+            return o
+
+        o = None
+        for _ in range(warmup):
+            o = one()
+        k_ms.clear(); p_ms.clear(); s_ms.clear(); aux.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = one()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return {"elapsed": el, "out": o, "kernel_ms": k_ms, "pipe_ms": p_ms, "step_ms": s_ms, "aux_ms": aux, "host": lhost,
+                "plan": X.last_plan() or {}, "psz": lpsz}
+
+    leg0 = timed_leg(wl, n_local, n_total, start, log2_total, args.steps, args.warmup)
+    host, out, plan, psz = leg0["host"], leg0["out"], leg0["plan"], leg0["psz"]
+    kernel_ms, pipe_ms, step_ms, elapsed = leg0["kernel_ms"], leg0["pipe_ms"], leg0["step_ms"], leg0["elapsed"]
 
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
     value = n_total / (ms_per_step * 1e-3)
@@ -321,23 +381,9 @@ def main():
     parity = None if gold is None else (out == gold)
 
     # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
-    # same command (counters cannot be read from inside the process); the summary is committed
-    # under profiles/ and only quoted when it was taken on the workload and kernel being run.
-    traffic, traffic_note = None, None
-    for tname in ("r02_traffic.json", "r01_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if not os.path.exists(tpath):
-            continue
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("workload") == wl and tj.get("log2n") == log2n and world == 1 and \
-                tj.get("kernel", plan.get("kernel")) == plan.get("kernel"):
-            traffic = tj["traffic_bytes_raw"]
-            traffic_note = ("PMC (FETCH_SIZE+WRITE_SIZE)*1024 per launch, raw; %.3g with the gfx950 x2 FETCH correction "
-                            "(calibrated for coalesced streams only; this kernel gathers 104-B limb records at a 168-B stride, one pass "
-                            "per window over a 176 MB point array that stays in the 256 MB Infinity Cache). Source: profiles/%s"
-                            % (tj["traffic_bytes_fetch_x2"], tj.get("source", tname)))
-        break
+    # same command; the summary is committed under profiles/ and only quoted when it was taken on
+    # the workload and kernel being run.
+    traffic, traffic_note = (None, None) if world > 1 else traffic_for(wl, log2n, (plan.get("kernel") or "").split("<")[0] if wl == "pairing" else plan.get("kernel"))
 
     result = None
     if rank == 0:
@@ -389,6 +435,14 @@ def main():
                 result["roofline_valu"]["mads_executed_per_addition"] = executed
                 result["roofline_valu"]["frac_executed"] = n_local * plan["windows"] * executed / (k_ms * 1e-3) / MAD_PEAK
 
+        if wl == "pairing" and k_ms > 0 and leg0["aux_ms"]:
+            ck = sum(a[0] for a in leg0["aux_ms"]) / len(leg0["aux_ms"])
+            fo = sum(a[1] for a in leg0["aux_ms"]) / len(leg0["aux_ms"])
+            result["roofline_valu"] = pairing_valu(n_local, k_ms, ck, fo, p_ms)
+        if wl in ("g1msm", "g2msm") and leg0["aux_ms"]:
+            result["roofline"]["sort_stage_ms"] = sum(a[0] for a in leg0["aux_ms"]) / len(leg0["aux_ms"])
+            result["roofline"]["fold_reduce_ms"] = sum(a[1] for a in leg0["aux_ms"]) / len(leg0["aux_ms"])
+
     # ---- the reference-ABI call itself: host buffer in, H2D inside the timed call
     if rank == 0 and world == 1 and not args.no_host_abi:
         hout, leg = host_abi_leg(X, wl, host, n_local, 3)
@@ -439,37 +493,66 @@ def main():
         d_p = torch.frombuffer(bytearray(ph), dtype=torch.uint8).cuda()
         pout = X.dev_call(FULL["pairing"], d_p.data_ptr(), k)
         torch.cuda.synchronize()
-        reps, kms, pms, tms = 5, [], [], []
+        reps, kms, pms, tms, cks, fos = 10, [], [], [], [], []
         for _ in range(reps):
             t1 = time.perf_counter()
             pout = X.dev_call(FULL["pairing"], d_p.data_ptr(), k)
             tms.append((time.perf_counter() - t1) * 1e3)
             pms.append(X.last_timing()[0])
             kms.append(X.last_timing()[1])
+            cks.append(X.last_timing_aux()[0])
+            fos.append(X.last_timing_aux()[1])
         pst = stats_ms(tms)
         pplan = X.last_plan() or {}
+        ptraffic, ptraffic_note = traffic_for("pairing", 12, (pplan.get("kernel") or "").split("<")[0])
         sec = {"metric": "pairing_pairs_per_sec", "value": k / (pst["mean"] * 1e-3), "unit": "pairs/s", "ms_per_check": pst,
                "value_median": k / (pst["median"] * 1e-3), "value_best": k / (pst["min"] * 1e-3),
                "pairs": k, "result_is_one": pout == bytes(31) + b"\x01",
                "mgas_per_s": X.gas("pairing", k * 384) / (pst["mean"] * 1e-3) / 1e6,
                "roofline": {"bound": "hbm", "kernel": pplan.get("kernel"), "achieved": 384 * k / (sum(kms) / reps * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 384 * k / (sum(kms) / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "kernel_ms": sum(kms) / reps, "device_pipeline_ms": sum(pms) / reps}}
+                            "traffic": ptraffic, "traffic_note": ptraffic_note, "kernel_ms": sum(kms) / reps,
+                            "device_pipeline_ms": sum(pms) / reps, "algorithmic_bytes_per_unit": 384, "units_per_launch": k},
+               "roofline_valu": pairing_valu(k, sum(kms) / reps, sum(cks) / reps, sum(fos) / reps, sum(pms) / reps)}
         if not args.no_host_abi:
             hout, leg = host_abi_leg(X, "pairing", ph, k, 3)
             leg["result_is_one"] = hout == bytes(31) + b"\x01"
             sec["host_abi"] = leg
         if not args.no_cpu_baseline:
             from oracle import clib
-            sk = 1024
-            samp = pairing_fixup(X, ph[:sk * 384], sk)
             t1 = time.perf_counter()
-            rc, cout = clib.call("bls12_pairing", samp)
+            rc, cout = clib.call("bls12_pairing", ph)
             dtc = time.perf_counter() - t1
-            sec["cpu_baseline"] = {"value": sk / dtc, "unit": "pairs/s", "cores": 1, "kind": "port",
-                                   "sample": "2^10-pair check, oracle bls12_pairing, %.1f s" % dtc,
-                                   "result_is_one": rc == 0 and cout == bytes(31) + b"\x01"}
+            sec["cpu_baseline"] = {"value": k / dtc, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": "the same 2^12-pair check, oracle bls12_pairing (reference control flow: sequential "
+                                             "membership tests and Miller loops, one final exponentiation), one run of %.1f s" % dtc,
+                                   "result_is_one": rc == 0 and cout == bytes(31) + b"\x01",
+                                   "gpu_matches_cpu_on_sample": rc == 0 and cout == pout}
         result["secondary"] = sec
+
+    # ---- N > 1: BASELINE config 5 literally -- ONE 2^20-record MSM and ONE 2^12-pair check sharded over the N GPUs
+    # (strong scaling), next to the weak-scaling headline above.  Every rank runs the legs; rank 0 reports.
+    if world > 1 and args.scaling == "weak" and not args.no_secondary:
+        strong = {}
+        for swl, slog in (("g1msm", 20), ("pairing", 12)):
+            sn_total = 1 << slog
+            if sn_total % world:
+                continue
+            sn_local = sn_total // world
+            sl = timed_leg(swl, sn_local, sn_total, rank * sn_local, slog, max(3, min(args.steps, 10)), 2)
+            nst = max(3, min(args.steps, 10))
+            sgold = bytes(31) + b"\x01" if swl == "pairing" else golden(swl, slog)
+            if rank == 0:
+                sms = sl["elapsed"] * 1e3 / nst
+                strong[swl] = {"metric": "%s_pairs_per_sec" % ("g1_msm" if swl == "g1msm" else "pairing"), "scaling": "strong",
+                               "records_total": sn_total, "records_per_gpu": sn_local, "n_gpus": world, "steps": nst,
+                               "ms_per_step": sms, "value": sn_total / (sms * 1e-3), "unit": "pairs/s",
+                               "bit_exact_vs_golden": None if sgold is None else sl["out"] == sgold,
+                               "shard_device_pipeline_ms": sum(sl["pipe_ms"]) / max(1, len(sl["pipe_ms"])),
+                               "note": "one %s over 2^%d records cut into %d contiguous shards; a shard of this size is mostly fixed chain "
+                                       "latency (DESIGN.md 6)" % (ORACLE[swl], slog, world)}
+        if rank == 0:
+            result["strong"] = strong
 
     # ---- N > 1: the same total input through the reference ABI of ONE process, cut over the N
     # devices inside the library (thread per device, host combine).  Runs in a fresh child of rank 0
@@ -491,7 +574,11 @@ def main():
         if rank == 0:
             store.set("eip2537_split_leg_done", "1")
         else:
-            store.wait(["eip2537_split_leg_done"])
+            import datetime
+            try:
+                store.wait(["eip2537_split_leg_done"], datetime.timedelta(seconds=900))     # longer than the child's own limit
+            except Exception as ex:                                 # the headline number must survive this leg
+                sys.stderr.write("bench.py rank %d: split leg wait: %r\n" % (rank, ex))
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -82,7 +82,7 @@ static std::atomic<int> g_window_override{0};
 static std::atomic<int> g_route_override{-1};        // -1 default, 0 always GPU, 1 always host (small-call tests)
 
 struct CallStats {
-    float pipeline_ms = 0.f, dominant_ms = 0.f;
+    float pipeline_ms = 0.f, dominant_ms = 0.f, aux_ms[2] = {0.f, 0.f};
     LastPlan plan{};
     bool valid = false;
 };
@@ -94,7 +94,16 @@ static CallStats g_last;
 // streams.  The variable is read when the runtime initialises, so it is set (never overriding the
 // embedder's own value) when this library is loaded -- before its first HIP call, and for a linked
 // binary before main() starts any thread -- instead of from inside a precompile call.
-__attribute__((constructor)) static void eip_library_loaded() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// (Round 3: the library no longer calls setenv itself -- through the static shim it is dlopen'ed lazily from caller
+// threads, where setenv races with getenv in the embedder's runtime.  The embedder sets GPU_MAX_HW_QUEUES=16 before its
+// first HIP call; blst_eip2537_amd/__init__.py, bench.py and the tests do; the first engine warns once
+// when it is unset.)
+static void warn_hw_queues_once() {
+    static std::atomic<bool> said{false};
+    if (!getenv("GPU_MAX_HW_QUEUES") && !said.exchange(true))
+        fprintf(stderr, "[eip2537_hip] note: GPU_MAX_HW_QUEUES is not set; concurrent callers share 4 hardware queues "
+                        "(set GPU_MAX_HW_QUEUES=16 before the first HIP call, see INTEGRATION.md)\n");
+}
 
 // Make `dev` current on this thread for the duration of a call and put the caller's device back
 // afterwards (an embedder such as torch keeps its own notion of the current device).
@@ -132,6 +141,7 @@ static bool device_select_locked() {
     g_ndev = ndev;
     int want[kMaxPools], nwant = 0;
     const char *list = getenv("EIP2537_HIP_DEVICES");
+    if (list && !*list) list = nullptr;                       // an empty value means "not set"
     if (g_device_request >= 0) {
         want[nwant++] = g_device_request;
     } else if (list && *list && strcmp(list, "all") != 0) {
@@ -170,13 +180,14 @@ static bool device_select_locked() {
 }
 static bool slot_init(Engine &e, int ordinal) {
     if (e.ready) return true;
+    warn_hw_queues_once();
     e.device = ordinal;
     bool ok = hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&e.stream3, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&e.ev_start) == hipSuccess && hipEventCreate(&e.ev_stop) == hipSuccess &&
               hipEventCreate(&e.ev_a) == hipSuccess && hipEventCreate(&e.ev_b) == hipSuccess &&
-              hipEventCreate(&e.ev_j2) == hipSuccess && hipEventCreate(&e.ev_j3) == hipSuccess;
+              hipEventCreate(&e.ev_j2) == hipSuccess && hipEventCreate(&e.ev_j3) == hipSuccess && hipEventCreate(&e.ev_c) == hipSuccess;
     if (!ok) { fprintf(stderr, "[eip2537_hip] FATAL: stream/event creation failed on device %d\n", ordinal); return false; }
     e.ready = true;
     e.failed = false;
@@ -191,7 +202,7 @@ static void slot_reset(Engine &e) {
     if (e.stream3) (void)hipStreamSynchronize(e.stream3);
     (void)hipGetLastError();
     for (hipStream_t *s : {&e.stream, &e.stream2, &e.stream3}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
-    for (hipEvent_t *v : {&e.ev_start, &e.ev_stop, &e.ev_a, &e.ev_b, &e.ev_j2, &e.ev_j3}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
+    for (hipEvent_t *v : {&e.ev_start, &e.ev_stop, &e.ev_a, &e.ev_b, &e.ev_j2, &e.ev_j3, &e.ev_c}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
     e.release_workspace();
     e.ready = false;
     e.failed = false;
@@ -235,6 +246,8 @@ struct SlotLease {
         if (idx < 0) return;
         t_last.pipeline_ms = e->last_kernel_ms;
         t_last.dominant_ms = e->last_accum_ms;
+        t_last.aux_ms[0] = e->last_aux_ms[0];
+        t_last.aux_ms[1] = e->last_aux_ms[1];
         t_last.plan = e->last_plan;
         t_last.valid = true;
         if (e->failed) slot_reset(*e);
@@ -516,11 +529,17 @@ static void coalesce(Req &req, size_t max_calls, size_t max_units, Run &&run) {
             b.pending.swap(rest);
             b.in_flight++;
             b.served += batch.size();
+            // requests the batch limits left behind can be led by one of their own callers as long as a flight is free
+            if (!b.pending.empty() && b.in_flight < coalesce_flights(b.served + b.pending.size())) b.cv.notify_all();
             lk.unlock();
             g_co_batches++;
             g_co_calls += batch.size();
             for (uint64_t m = g_co_max.load(); batch.size() > m && !g_co_max.compare_exchange_weak(m, batch.size());) {}
-            run(batch);
+            try {
+                run(batch);
+            } catch (...) {                 // std::bad_alloc in a leader must not strand its followers or cross the C ABI
+                for (Req *r : batch) r->rc = E_MEMORY_ERROR;
+            }
             lk.lock();
             b.in_flight--;
             b.served -= batch.size();
@@ -923,6 +942,12 @@ API void eip2537_hip_last_timing(float *pipeline_ms, float *dominant_kernel_ms) 
     if (pipeline_ms) *pipeline_ms = c.pipeline_ms;
     if (dominant_kernel_ms) *dominant_kernel_ms = c.dominant_ms;
 }
+API void eip2537_hip_last_timing_aux(float *aux1_ms, float *aux2_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const CallStats &c = t_last.valid ? t_last : g_last;
+    if (aux1_ms) *aux1_ms = c.aux_ms[0];
+    if (aux2_ms) *aux2_ms = c.aux_ms[1];
+}
 API int eip2537_hip_last_plan(char *kernel_name, size_t cap, int *window_bits, int *windows, int *lanes,
                               uint32_t *units, uint32_t *buckets) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -973,6 +998,8 @@ API int eip2537_hip_set_window(int c) {
     return 0;
 }
 
+// EIP_HOST_ONLY: the ThreadSanitizer build of this file's host concurrency code (tools/tsan/) has no device code at all
+#ifndef EIP_HOST_ONLY
 // Device self-test of the field products: n pseudo-random operand pairs (every eighth pair from a table
 // of extreme values) through the column products the kernels use -- canonical and lazy, product and
 // square -- against the independent 12 x 32-bit CIOS product, all on the device. Guards the products
@@ -1102,6 +1129,11 @@ API int eip2537_hip_limb_selftest(uint64_t seed, size_t n, uint64_t mismatches[8
     for (int k = 0; k < 8; k++) mismatches[k] = h_bad[k];
     return 0;
 }
+
+#else
+API int eip2537_hip_field_selftest(uint64_t, size_t, uint64_t *) { return E_MEMORY_ERROR; }
+API int eip2537_hip_limb_selftest(uint64_t, size_t, uint64_t *) { return E_MEMORY_ERROR; }
+#endif
 
 // Synthetic workloads of SURVEY.md 8d (host code; used by bench.py and the tests, never by a precompile)
 API int eip2537_hip_gen_g1_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t seed, uint64_t start) {

@@ -31,7 +31,7 @@ struct Engine {
     bool failed = false;   // a HIP call failed mid-pipeline: the slot is drained and rebuilt on release
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr, ev_c = nullptr;
     // staging + per-call workspace (grow-only)
     DevBuf input;          // H2D copy of a host caller's records
     const void *host_src = nullptr;   // set by a host-input MSM call: the pipeline stages `input` from here itself, in chunks (msm.hip)
@@ -51,6 +51,7 @@ struct Engine {
     // last-call kernel timing (ms), filled when timing is enabled
     float last_kernel_ms = 0.f;   // whole device pipeline of the last call
     float last_accum_ms = 0.f;    // dominant kernel of the last call (named in last_plan.kernel)
+    float last_aux_ms[2] = {0.f, 0.f};   // pairing: G1 membership kernel, line products (fold + tree2); MSM: sort stage (decode .. task order), fold + reduce
     LastPlan last_plan{};
 
     template <class Fn> void for_each_buf(Fn &&fn) {
@@ -59,6 +60,14 @@ struct Engine {
     }
     size_t workspace_bytes() { size_t t = 0; for_each_buf([&](DevBuf &b) { t += b.cap; }); return t; }
     void release_workspace() { for_each_buf([](DevBuf &b) { b.release(); }); }
+};
+
+// Async device-to-host copies target host objects owned by the calling frame: if a later HIP call fails and the function
+// returns early, the stream is drained first so that no copy is still writing into a dead stack / vector.
+struct StreamDrain {
+    hipStream_t s;
+    bool armed = true;
+    ~StreamDrain() { if (armed) (void)hipStreamSynchronize(s); }
 };
 
 // Window plan for one MSM

@@ -1332,12 +1332,16 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
 
     unsigned long long herr = 0;
     std::vector<Xyzz<F>> hw(nwin_out);
+    StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hw.data(), winout, nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    drain.armed = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
+    if (hipEventElapsedTime(&ms, e->ev_start, e->ev_a) == hipSuccess) e->last_aux_ms[0] = ms;     // decode .. task order
+    if (hipEventElapsedTime(&ms, e->ev_b, e->ev_stop) == hipSuccess) e->last_aux_ms[1] = ms;      // fold + bucket reduce
     if (herr != ~0ull) return (int)(herr & 7ull);
 
     // Horner over windows on the host (W * c doublings + a handful of additions)
@@ -1544,9 +1548,11 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
 
     std::vector<unsigned long long> herr((size_t)M);
     std::vector<Xyzz<F>> hw(units);
+    StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(herr.data(), err, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hw.data(), winout, (size_t)units * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    drain.armed = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;

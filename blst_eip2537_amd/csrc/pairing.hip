@@ -482,18 +482,23 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipLaunchKernelGGL(k_pair_fold<false>, dim3(tree_blocks, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)nullptr,
                        blk_out, step_out, tree_blocks == 1 ? 1 : 0);
     if (tree_blocks > 1) hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(256), 0, s, blk_out, tree_blocks, step_out);
+    HIPCHK(hipEventRecord(e->ev_c, s));
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
     unsigned long long herr = 0;
     std::vector<Fp12> L(kSteps);
+    StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(&herr, b.err, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    drain.armed = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
+    if (hipEventElapsedTime(&ms, e->ev_j3, e->ev_j2) == hipSuccess) e->last_aux_ms[0] = ms;      // decode done -> membership done
+    if (hipEventElapsedTime(&ms, e->ev_b, e->ev_c) == hipSuccess) e->last_aux_ms[1] = ms;        // walk done -> L_s written
     if (herr != ~0ull) return (int)(herr & 7ull);
     const Fp12 F = miller_product_from_steps(L.data());
     memcpy(ml_words, &F, sizeof F);
@@ -526,9 +531,11 @@ int pairing_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int 
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
     std::vector<unsigned long long> herr((size_t)M);
+    StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(herr.data(), b.err, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(L_words, step_out, (size_t)M * kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    drain.armed = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;

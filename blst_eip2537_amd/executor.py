@@ -9,6 +9,11 @@ include/eip2537_hip.h are exposed as *_dev / *_partial_dev / *_combine.
 import ctypes
 import os
 
+# Concurrent callers drive up to 8 engine slots x 3 streams; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+# queues (4 unless told otherwise) when it initialises, so the variable has to be in the environment before the first HIP
+# call of the process.  The library itself no longer touches the environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EIP2537_HIP_LIB: load another build of the same library (kernel A/B runs); default is the in-tree one
 _SO = os.environ.get("EIP2537_HIP_LIB") or os.path.join(_HERE, "libeip2537_hip.so")
@@ -105,6 +110,8 @@ def lib():
     L.eip2537_hip_last_plan.restype = ctypes.c_int
     L.eip2537_hip_last_plan.argtypes = [ctypes.c_char_p, ctypes.c_size_t] + [ctypes.POINTER(ctypes.c_int)] * 3 + \
                                        [ctypes.POINTER(ctypes.c_uint32)] * 2
+    L.eip2537_hip_last_timing_aux.restype = None
+    L.eip2537_hip_last_timing_aux.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.eip2537_hip_last_timing.restype = None
     L.eip2537_hip_last_timing.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     _lib = L
@@ -214,6 +221,14 @@ class Eip2537Executor:
     def last_timing():
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         lib().eip2537_hip_last_timing(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    @staticmethod
+    def last_timing_aux():
+        """Two more device intervals of the last GPU call in ms (eip2537_hip.h): pairing (G1 membership kernel, line
+        products), MSM (sort stage, fold + bucket reduce)."""
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        lib().eip2537_hip_last_timing_aux(ctypes.byref(a), ctypes.byref(b))
         return a.value, b.value
 
     @staticmethod

@@ -60,6 +60,10 @@ int eip2537_hip_pairing_combine(uint8_t out[32], const uint8_t *partials, size_t
  * (the bucket accumulate of an MSM, the line walk of a pairing batch -- named by
  * eip2537_hip_last_plan).  For a call split over several devices: the slowest shard. */
 void eip2537_hip_last_timing(float *pipeline_ms, float *dominant_kernel_ms);
+/* Two more intervals of the same call, from HIP events on the engine's streams.  Pairing: aux1 = the G1 membership kernel
+ * (second stream, beside the line walk), aux2 = the per-step line products (k_pair_fold + k_pair_tree2).  MSM: aux1 = the
+ * sort stage (decode, histograms, scans, scatter, task order), aux2 = fold + bucket reduce. */
+void eip2537_hip_last_timing_aux(float *aux1_ms, float *aux2_ms);
 /* What that call ran: the dominant kernel's name as rocprofv3 prints it, the Pippenger window width
  * and window count (pairing: 0 and the 68 Miller steps), lanes per task / pair, the records / pairs
  * of the launch and the bucket count.  Any pointer may be NULL.  Returns 0, or EIP2537_EMPTY_INPUT
