@@ -290,15 +290,16 @@ struct TreeShared {
     uint32_t scratch[kScratchLimbStrings * kLimbStride];
 };
 // one level of the pairwise product: element 2 i * stride *= element (2 i + 1) * stride, i < nprod
-template <int UPL> __device__ __forceinline__ void dense_level(TreeShared &sh, int stride, int nprod, int tid) {
+// the products of one level: product pr multiplies element left(pr) by element right(pr) in place (right == left squares it)
+template <int UPL, class Left, class Right> __device__ __forceinline__ void dense_products(TreeShared &sh, int nprod, int tid, Left left, Right right) {
     constexpr int LP = 72 / UPL, PARTS = 6 / UPL, PER_PASS = 256 / LP;
     static_assert(UPL == 6 || PER_PASS * 12 * PARTS <= kScratchLimbStrings, "scratch too small");
     const int slot = tid / LP, idx = tid % LP, o = idx / PARTS, part = idx % PARTS;
     for (int p0 = 0; p0 < nprod; p0 += PER_PASS) {                 // uniform
         const int pr = p0 + slot;
         const bool active = slot < PER_PASS && pr < nprod;
-        uint32_t *f = sh.elems + (size_t)(2 * pr) * stride * kElemWords;
-        const uint32_t *g = f + (size_t)stride * kElemWords;
+        uint32_t *f = sh.elems + (size_t)left(active ? pr : 0) * kElemWords;
+        const uint32_t *g = sh.elems + (size_t)right(active ? pr : 0) * kElemWords;
         FpL acc = fpl_zero();
         if (active) {
             acc = dense_terms<UPL>(f, g, o >> 1, o & 1, part * UPL).l[0];
@@ -324,14 +325,18 @@ template <int UPL> __device__ __forceinline__ void dense_level(TreeShared &sh, i
         __syncthreads();
     }
 }
-// product of the first `live` elements of sh.elems (each <= 3 p), left in element 0
-__device__ __forceinline__ void block_tree(TreeShared &sh, int live, int tid) {
+template <class Left, class Right> __device__ __forceinline__ void dense_products_auto(TreeShared &sh, int nprod, int tid, Left left, Right right) {
+    if (nprod > 10) dense_products<6>(sh, nprod, tid, left, right);          // lanes per product: as many as the block has for them
+    else if (nprod > 7) dense_products<3>(sh, nprod, tid, left, right);
+    else if (nprod > 3) dense_products<2>(sh, nprod, tid, left, right);
+    else dense_products<1>(sh, nprod, tid, left, right);
+}
+// `regions` runs of `live` elements each, region r at element r * pitch: every run is multiplied down into its first element
+__device__ __forceinline__ void block_tree(TreeShared &sh, int live, int tid, int regions = 1, int pitch = 0) {
     for (int stride = 1; stride < live; stride <<= 1) {
-        const int ne = (live + stride - 1) / stride, nprod = ne / 2;
-        if (nprod > 10) dense_level<6>(sh, stride, nprod, tid);
-        else if (nprod > 7) dense_level<3>(sh, stride, nprod, tid);
-        else if (nprod > 3) dense_level<2>(sh, stride, nprod, tid);
-        else dense_level<1>(sh, stride, nprod, tid);
+        const int ne = (live + stride - 1) / stride, per = ne / 2;
+        dense_products_auto(sh, per * regions, tid, [=](int pr) { return (pr / per) * pitch + 2 * (pr % per) * stride; },
+                            [=](int pr) { return (pr / per) * pitch + (2 * (pr % per) + 1) * stride; });
     }
 }
 // element -> the host's Fp12 (12 x 32-bit words, Montgomery factor 2^384, canonical), tower layout
@@ -402,15 +407,26 @@ k_pair_fold(const LineL *__restrict__ lines, const PairPL *__restrict__ pl, uint
     else copy_elem(blk_out + ((size_t)s * gridDim.x + blockIdx.x) * kElemWords, sh.elems, tid);
 }
 
-// one block per step: product of the per-block elements -> L_s in the host layout
+// One block per GROUP of kGroupSteps consecutive Miller steps: the per-block elements of each step are multiplied down to
+// L_s (the steps of the group side by side), and then the group's own share of the host's Horner pass is done here:
+//     M = prod_i L_{s_i}^(2^{e_i}),   e_i = doublings after step s_i inside the group       (acc = acc^2 . L for a doubling step)
+// so that the host squares 63 times as before but multiplies 17 times instead of 68 (F = F^(2^E) M per group): the
+// products it no longer does were a third of its 0.6 ms; here they are a few dense products on 72 lanes each.
+static constexpr int kGroupSteps = 4, kGroups = (kSteps + kGroupSteps - 1) / kGroupSteps, kGroupPitch = 8;
 __global__ void __launch_bounds__(256)
-k_pair_tree2(const uint32_t *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ step_out) {
+k_pair_tree2(const uint32_t *__restrict__ blk_out, uint32_t nblk, Fp2 *__restrict__ group_out) {
     __shared__ TreeShared sh;
-    const int s = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t t = tid; t < nblk * kElemWords; t += 256) sh.elems[t] = blk_out[(size_t)s * nblk * kElemWords + t];
+    const int g = blockIdx.x, tid = threadIdx.x, s0 = g * kGroupSteps, m = min(kGroupSteps, kSteps - s0);
+    for (int r = 0; r < m; r++)
+        for (uint32_t t = tid; t < nblk * kElemWords; t += 256)
+            sh.elems[(size_t)r * kGroupPitch * kElemWords + t] = blk_out[(size_t)(s0 + r) * nblk * kElemWords + t];
     __syncthreads();
-    block_tree(sh, (int)nblk, tid);
-    emit_fp12(sh.elems, step_out + (size_t)s * 6, tid);
+    block_tree(sh, (int)nblk, tid, m, kGroupPitch);                         // element r * pitch = L_{s0 + r}
+    for (int r = 1; r < m; r++) {                                           // uniform
+        if (!step_is_add(s0 + r)) dense_products<1>(sh, 1, tid, [](int) { return 0; }, [](int) { return 0; });
+        dense_products<1>(sh, 1, tid, [](int) { return 0; }, [=](int) { return r * kGroupPitch; });
+    }
+    emit_fp12(sh.elems, group_out + (size_t)g * 6, tid);
 }
 
 // Decode, membership and line walk of K pairs that belong to M calls (M = 1: one call, no table): the
@@ -478,20 +494,19 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipStream_t s = e->stream;
     st = pairing_front(e, reinterpret_cast<const uint32_t *>(d_in), k, nullptr, 1, b);
     if (st) return st;
-    // one block per step: its product IS L_s
     hipLaunchKernelGGL(k_pair_fold<false>, dim3(tree_blocks, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)nullptr,
-                       blk_out, step_out, tree_blocks == 1 ? 1 : 0);
-    if (tree_blocks > 1) hipLaunchKernelGGL(k_pair_tree2, dim3(kSteps), dim3(256), 0, s, blk_out, tree_blocks, step_out);
+                       blk_out, step_out, 0);
+    hipLaunchKernelGGL(k_pair_tree2, dim3(kGroups), dim3(256), 0, s, blk_out, tree_blocks, step_out);     // step_out: one Fp12 per group of steps
     HIPCHK(hipEventRecord(e->ev_c, s));
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
     unsigned long long herr = 0;
-    std::vector<Fp12> L(kSteps);
+    std::vector<Fp12> L(kGroups);
     StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(&herr, b.err, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kSteps * sizeof(Fp12), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kGroups * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     drain.armed = false;
     float ms = 0.f;
@@ -500,7 +515,14 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     if (hipEventElapsedTime(&ms, e->ev_j3, e->ev_j2) == hipSuccess) e->last_aux_ms[0] = ms;      // decode done -> membership done
     if (hipEventElapsedTime(&ms, e->ev_b, e->ev_c) == hipSuccess) e->last_aux_ms[1] = ms;        // walk done -> L_s written
     if (herr != ~0ull) return (int)(herr & 7ull);
-    const Fp12 F = miller_product_from_steps(L.data());
+    // F = F^(2^E) M per group, E = the doubling steps of the group (63 squarings and 17 products in all)
+    Fp12 F = fp12_one();
+    for (int g = 0; g < kGroups; g++) {
+        for (int s2 = g * kGroupSteps; s2 < std::min(kSteps, (g + 1) * kGroupSteps); s2++)
+            if (!step_is_add(s2) && s2 > 0) F = sqr(F);                     // (the very first squaring is of one)
+        F = g == 0 ? L[0] : mul(F, L[(size_t)g]);
+    }
+    F = conj(F);
     memcpy(ml_words, &F, sizeof F);
     return E_SUCCESS;
 }
