@@ -22,6 +22,7 @@
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
+#include "ifma.h"
 #include "h2c.h"
 #include "limbk.h"
 #include "engine.h"
@@ -650,7 +651,7 @@ template <class F> static int msm_combine(byte *out, const uint8_t *partials, si
 }
 
 static void pairing_finish(byte *out, const Fp12 &ml) {
-    bool one = is_one(final_exp(ml));
+    bool one = is_one(final_exp_host(ml));
     memset(out, 0, 32);
     if (one) out[31] = 1;
 }

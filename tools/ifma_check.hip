@@ -1,0 +1,88 @@
+// Host check of csrc/ifma.h (AVX-512 IFMA arithmetic of the pairing's host tail) against the scalar code of pairing.h.
+//   hipcc -O2 -std=c++17 --offload-arch=gfx950 -Xarch_host -mbmi2 -Xarch_host -madx -Iblst_eip2537_amd/csrc tools/ifma_check.hip -o /tmp/ifma_check
+#include <stdio.h>
+#include <chrono>
+#include <hip/hip_runtime.h>
+#include "pairing.h"
+#include "ifma.h"
+using namespace eip;
+static uint64_t g_s = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() { g_s ^= g_s << 13; g_s ^= g_s >> 7; g_s ^= g_s << 17; return g_s; }
+static Fp rnd_fp() { Fp v; for (int k = 0; k < 12; k++) v.l[k] = (uint32_t)rnd(); v.l[11] &= 0x0fffffffu; return mul(v, fp_one()); }
+static Fp2 r2() { return Fp2{rnd_fp(), rnd_fp()}; }
+static Fp12 r12() { return Fp12{Fp6{r2(), r2(), r2()}, Fp6{r2(), r2(), r2()}}; }
+#if defined(EIP_HAVE_IFMA)
+__attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl,avx512bw"))) static int run() {
+    using namespace ifma;
+    long bad = 0;
+    for (int it = 0; it < 20000; it++) {
+        Fp a[8], b[8], out[8];
+        const Fp *pa[8], *pb[8];
+        Fp *po[8];
+        for (int i = 0; i < 8; i++) {
+            a[i] = rnd_fp(); b[i] = rnd_fp();
+            if (it % 5 == 0 && i == 3) { a[i] = fp_zero(); }
+            if (it % 7 == 0 && i == 5) { a[i] = sub(fp_zero(), fp_one()); b[i] = a[i]; }       // p - 1 (in Montgomery form: -1)
+            pa[i] = &a[i]; pb[i] = &b[i]; po[i] = &out[i];
+        }
+        const V8 va = vload(pa), vb = vload(pb);
+        vstore(po, va);
+        for (int i = 0; i < 8; i++) if (!eq(out[i], a[i])) bad++;
+        vstore(po, vmul(va, vb));
+        for (int i = 0; i < 8; i++) if (!eq(out[i], mul(a[i], b[i]))) bad++;
+        // lazy chains: (a + b)(a - b + 64 p), reduced
+        vstore(po, vmul(vnorm(vadd(va, vb)), vnorm(vsub64(va, vb))));
+        for (int i = 0; i < 8; i++) if (!eq(out[i], mul(add(a[i], b[i]), sub(a[i], b[i])))) bad++;
+        V8 big = va;
+        for (int k = 0; k < 9; k++) big = vadd(big, big);                 // 512 a
+        vstore(po, vreduce(vnorm(big)));
+        for (int i = 0; i < 8; i++) {
+            Fp w = a[i];
+            for (int k = 0; k < 9; k++) w = add(w, w);
+            if (!eq(out[i], w)) bad++;
+        }
+    }
+    printf("vector field operations: %ld mismatches\n", bad);
+    long bad2 = 0;
+    for (int it = 0; it < 300; it++) {
+        Fp12 f = r12();
+        Fp12 want = f;
+        Cyc c = cyc_load(f);
+        for (int k = 0; k < 40; k++) {
+            want = cyclotomic_sqr(want);
+            c = cyc_sqr(c);
+            if (k % 13 == 0 && !eq(cyc_store(c), want)) { bad2++; break; }
+        }
+        if (!eq(cyc_store(c), want)) bad2++;
+    }
+    printf("cyclotomic squaring chains: %ld mismatches\n", bad2);
+    long bad3 = 0;
+    for (int it = 0; it < 20; it++) {
+        // an element of the cyclotomic subgroup: the easy part of the final exponentiation of a random element
+        const Fp12 f = r12();
+        const Fp12 f1 = mul(conj(f), inv(f)), g = mul(frob2(f1), f1);
+        if (!eq(conj(exp_by_zabs_ifma(g)), exp_by_z(g))) bad3++;
+    }
+    printf("exponentiation by z: %ld mismatches\n", bad3);
+    // timing
+    Fp12 f = r12();
+    const Fp12 f1 = mul(conj(f), inv(f)), g = mul(frob2(f1), f1);
+    auto t0 = std::chrono::steady_clock::now();
+    Fp12 x = g;
+    for (int i = 0; i < 200; i++) x = exp_by_z(x);
+    auto t1 = std::chrono::steady_clock::now();
+    Fp12 y = g;
+    for (int i = 0; i < 200; i++) y = conj(exp_by_zabs_ifma(y));
+    auto t2 = std::chrono::steady_clock::now();
+    printf("exp_by_z: scalar %.1f us, ifma %.1f us (%s)\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / 200,
+           std::chrono::duration<double, std::micro>(t2 - t1).count() / 200, eq(x, y) ? "equal" : "DIFFERENT");
+    return (bad || bad2 || bad3 || !eq(x, y)) ? 1 : 0;
+}
+#else
+static int run() { return 0; }
+namespace eip { namespace ifma { static bool cpu_has_ifma() { return false; } } }
+#endif
+int main() {
+    if (!ifma::cpu_has_ifma()) { printf("no AVX-512 IFMA on this CPU: skipped\n"); return 0; }
+    return run();
+}
