@@ -30,6 +30,7 @@
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
+#include "ifma.h"
 #include "lanes.h"
 #include "pairing_limb.h"
 #include "engine.h"
@@ -517,9 +518,17 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     if (herr != ~0ull) return (int)(herr & 7ull);
     // F = F^(2^E) M per group, E = the doubling steps of the group (63 squarings and 17 products in all)
     Fp12 F = fp12_one();
+    int nsq[kGroups];
     for (int g = 0; g < kGroups; g++) {
-        for (int s2 = g * kGroupSteps; s2 < std::min(kSteps, (g + 1) * kGroupSteps); s2++)
-            if (!step_is_add(s2) && s2 > 0) F = sqr(F);                     // (the very first squaring is of one)
+        nsq[g] = 0;
+        for (int s2 = g * kGroupSteps; s2 < std::min(kSteps, (g + 1) * kGroupSteps); s2++) nsq[g] += step_is_add(s2) ? 0 : 1;
+    }
+#if defined(EIP_HAVE_IFMA)
+    if (host_ifma_enabled()) F = ifma::horner_groups_ifma(L.data(), nsq, kGroups);          // AVX-512 IFMA: 0.4 us per Fp12 product
+    else
+#endif
+    for (int g = 0; g < kGroups; g++) {
+        for (int k2 = 0; k2 < nsq[g] && g > 0; k2++) F = sqr(F);          // (the squarings before the first group are of one)
         F = g == 0 ? L[0] : mul(F, L[(size_t)g]);
     }
     F = conj(F);

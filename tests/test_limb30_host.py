@@ -36,3 +36,21 @@ def test_pairing_lane_code_matches_host_arithmetic(tmp_path):
     for part in ("helpers", "G1 projective operations", "G1 membership", "Miller walk / G2 membership", "quad line products",
                  "dense products"):
         assert part + ": 0 mismatches" in out.stdout, out.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_host_ifma_arithmetic_matches_scalar(tmp_path):
+    """csrc/ifma.h (AVX-512 IFMA: eight Fp products per instruction, vector Fp12 products, cyclotomic squarings, the whole hard
+    part of the final exponentiation and the Horner pass over a batch's per-group products) against the scalar code of
+    pairing.h (tools/ifma_check.hip).  On a CPU without AVX-512 IFMA the tool reports that and the product uses the scalar code."""
+    exe = str(tmp_path / "ifma_check")
+    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "--offload-arch=gfx950", "-Xarch_host", "-mbmi2", "-Xarch_host", "-madx",
+                           "-I" + os.path.join(ROOT, "blst_eip2537_amd", "csrc"), os.path.join(ROOT, "tools", "ifma_check.hip"),
+                           "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    if "skipped" in out.stdout:
+        pytest.skip("no AVX-512 IFMA on this CPU")
+    for part in ("vector field operations", "cyclotomic squaring chains", "Fp12 products",
+                 "exponentiation by z, final exponentiation, Horner"):
+        assert part + ": 0 mismatches" in out.stdout, out.stdout

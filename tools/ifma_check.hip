@@ -57,26 +57,55 @@ __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl,avx512bw"))) static 
     }
     printf("cyclotomic squaring chains: %ld mismatches\n", bad2);
     long bad3 = 0;
-    for (int it = 0; it < 20; it++) {
+    for (int it = 0; it < 400; it++) {
+        const Fp12 f = r12(), g = r12();
+        const F12v vf = f12_load(f), vg = f12_load(g);
+        if (!eq(f12_store(vf), f)) bad3++;
+        if (!eq(f12_store(f12_mul(vf, vg)), mul(f, g))) bad3++;
+        if (!eq(f12_store(f12_mul(vf, vf)), sqr(f))) bad3++;
+        if (!eq(f12_store(f12_conj(vf)), conj(f))) bad3++;
+        if (!eq(f12_store(f12_mul(f12_conj(f12_mul(vf, vg)), f12_conj(vg))), mul(conj(mul(f, g)), conj(g)))) bad3++;    // chained, lazily reduced operands
+        if (!eq(f12_store(from_cyc(cyc_sqr(to_cyc(f12_load(f))))), cyclotomic_sqr(f))) bad3++;
+    }
+    printf("Fp12 products: %ld mismatches\n", bad3);
+    long bad4 = 0;
+    for (int it = 0; it < 12; it++) {
         // an element of the cyclotomic subgroup: the easy part of the final exponentiation of a random element
         const Fp12 f = r12();
         const Fp12 f1 = mul(conj(f), inv(f)), g = mul(frob2(f1), f1);
-        if (!eq(conj(exp_by_zabs_ifma(g)), exp_by_z(g))) bad3++;
+        if (!eq(conj(f12_store(f12_exp_zabs(f12_load(g)))), exp_by_z(g))) bad4++;
+        if (!eq(final_exp_ifma(f), final_exp(f))) bad4++;
+        Fp12 L[17];
+        int sq[17];
+        Fp12 want = fp12_one();
+        for (int k = 0; k < 17; k++) {
+            L[k] = r12();
+            sq[k] = k ? 1 + (int)(rnd() % 4) : 0;
+            for (int e = 0; e < sq[k]; e++) want = sqr(want);
+            want = k ? mul(want, L[k]) : L[0];
+        }
+        if (!eq(horner_groups_ifma(L, sq, 17), want)) bad4++;
     }
-    printf("exponentiation by z: %ld mismatches\n", bad3);
+    printf("exponentiation by z, final exponentiation, Horner: %ld mismatches\n", bad4);
     // timing
     Fp12 f = r12();
-    const Fp12 f1 = mul(conj(f), inv(f)), g = mul(frob2(f1), f1);
     auto t0 = std::chrono::steady_clock::now();
-    Fp12 x = g;
-    for (int i = 0; i < 200; i++) x = exp_by_z(x);
+    Fp12 x = f;
+    for (int i = 0; i < 50; i++) x = final_exp(x);
     auto t1 = std::chrono::steady_clock::now();
-    Fp12 y = g;
-    for (int i = 0; i < 200; i++) y = conj(exp_by_zabs_ifma(y));
+    Fp12 y = f;
+    for (int i = 0; i < 50; i++) y = final_exp_ifma(y);
     auto t2 = std::chrono::steady_clock::now();
-    printf("exp_by_z: scalar %.1f us, ifma %.1f us (%s)\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / 200,
-           std::chrono::duration<double, std::micro>(t2 - t1).count() / 200, eq(x, y) ? "equal" : "DIFFERENT");
-    return (bad || bad2 || bad3 || !eq(x, y)) ? 1 : 0;
+    F12v v = f12_load(f);
+    for (int i = 0; i < 2000; i++) v = f12_mul(v, v);
+    auto t3 = std::chrono::steady_clock::now();
+    Cyc c = to_cyc(f12_load(f));
+    for (int i = 0; i < 2000; i++) c = cyc_sqr(c);
+    auto t4 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    printf("final_exp: scalar %.1f us, ifma %.1f us (%s); vector Fp12 product %.3f us, cyclotomic squaring %.3f us (%d)\n", us(t0, t1) / 50, us(t1, t2) / 50,
+           eq(x, y) ? "equal" : "DIFFERENT", us(t2, t3) / 2000, us(t3, t4) / 2000, (int)(_mm512_reduce_add_epi64(v.c0.l[0]) + _mm512_reduce_add_epi64(c.c0.l[0])) & 1);
+    return (bad || bad2 || bad3 || bad4 || !eq(x, y)) ? 1 : 0;
 }
 #else
 static int run() { return 0; }
