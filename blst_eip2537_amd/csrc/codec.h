@@ -74,6 +74,51 @@ template <class F> HD int decode_point(Aff<F> &out, const uint32_t *w) {
     if (!on_curve(out)) return E_NOT_ON_CURVE;
     return E_SUCCESS;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same decode with every product INLINED, for the decode kernels: a call of the out-of-line Fp product costs the
+// calling kernel 160 B of scratch per lane for the callee's saved registers (k_msm_decode<Fp2>, k_msm_decode_batch and
+// k_pair_decode carried it through round 2).  Same verdicts in the same order as decode_point().
+__device__ __forceinline__ int fp_decode_inl(Fp &out, const uint32_t *w) {
+    const Fp p = fp_p();
+    const uint32_t pad = w[0] | w[1] | w[2] | w[3];
+    Fp raw;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        raw.l[11 - k] = bswap32(w[4 + k]);
+        nz |= w[4 + k];
+    }
+    uint32_t borrow = 0;     // raw < p  <=>  raw - p borrows
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const uint64_t s = (uint64_t)raw.l[i] - p.l[i] - borrow;
+        borrow = (uint32_t)(s >> 32) & 1u;
+    }
+    if (pad != 0 || borrow == 0) return -1;
+    out = fp_mul_cols(raw, Fp{{K_RR}});
+    return nz != 0;
+}
+__device__ __forceinline__ int fp_decode_inl(Fp2 &out, const uint32_t *w) {
+    const int s0 = fp_decode_inl(out.c0, w), s1 = fp_decode_inl(out.c1, w + 16);
+    if (s0 < 0 || s1 < 0) return -1;
+    return s0 | s1;
+}
+__device__ __forceinline__ bool on_curve_inl(const Aff<Fp> &a) {
+    return eq(fp_sqr_cols(a.y), add(fp_mul_cols(fp_sqr_cols(a.x), a.x), curve_b<Fp>()));
+}
+__device__ __forceinline__ bool on_curve_inl(const Aff<Fp2> &a) {
+    return eq(fp2_sqr_body(a.y), add(fp2_mul_body(fp2_sqr_body(a.x), a.x), curve_b<Fp2>()));
+}
+template <class F> __device__ __forceinline__ int decode_point_inl(Aff<F> &out, const uint32_t *w) {
+    const int sx = fp_decode_inl(out.x, w), sy = fp_decode_inl(out.y, w + Wire<F>::kCoordWords);
+    if (sx < 0 || sy < 0) return E_INVALID_ELEMENT;
+    if (sx == 0 && sy == 0) { out.x = f_zero<F>(); out.y = f_zero<F>(); return E_SUCCESS; }
+    if (!on_curve_inl(out)) return E_NOT_ON_CURVE;
+    return E_SUCCESS;
+}
+#else
+template <class F> HD int decode_point_inl(Aff<F> &out, const uint32_t *w) { return decode_point<F>(out, w); }     // the host pass only parses the kernels
+#endif
 template <class F> HD void encode_point(uint32_t *w, const Aff<F> &a) {
     fp_encode(w, a.x);
     fp_encode(w + Wire<F>::kCoordWords, a.y);

@@ -167,7 +167,7 @@ __device__ __forceinline__ int decode_point_limbs(PtL *dst, const uint32_t *w, b
     if (sx < 0 || sy < 0) return E_INVALID_ELEMENT;
     if (sx == 0 && sy == 0) return E_SUCCESS;
     const Fp k{{K_R384_R390_MODP}};
-    const Fp xm = mul(xr, k), ym = mul(yr, k);                    // x R', y R', canonical
+    const Fp xm = fp_mul_cols(xr, k), ym = fp_mul_cols(yr, k);    // x R', y R', canonical (inlined: no out-of-line call in the decode kernels)
     const FpL xl = to_limbs(xm), yl = to_limbs(ym);
     const FpL rhs = addL(mulL(sqrL(xl), xl), FpL{{K_B1_R390_30}});      // x^3 + 4 in the R' world, < 3p
     if (!is_zero_modp(subL<3>(sqrL(yl), rhs), 5)) return E_NOT_ON_CURVE;
@@ -193,7 +193,7 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
             st = decode_point_limbs(&ptl[i], w, live);
         } else {
             Aff<F> a;
-            st = decode_point<F>(a, w);
+            st = decode_point_inl<F>(a, w);
             if (st == E_SUCCESS && !is_inf(a)) {
                 pts[i] = a;
                 live = true;
@@ -754,7 +754,7 @@ k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ ta
         Xyzz<T> acc = partial[t0];
         for (uint32_t t = t0 + 1; t < t1; t++) {
             Xyzz<T> pt = partial[t];
-            xyzz_add_o<T>(&acc, &acc, &pt);
+            pt_add(acc, acc, pt);                      // inline for limb-form points, out of line otherwise
         }
         partial[t0] = acc;
     }
@@ -773,16 +773,16 @@ k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ task
         Xyzz<T> acc = xyzz_inf<T>();
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
             Xyzz<T> pt = partial[t];
-            xyzz_add_o<T>(&acc, &acc, &pt);
+            pt_add(acc, acc, pt);                      // inline for limb-form points, out of line otherwise
         }
         for (int off = 32; off >= 1; off >>= 1) {
             Xyzz<T> o = shfl_down(acc, off);
-            if (lane < off) xyzz_add_o<T>(&acc, &acc, &o);
+            if (lane < off) pt_add(acc, acc, o);
         }
         if (lane == 0) sm[wave] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 1; k < 4; k++) xyzz_add_o<T>(&acc, &acc, &sm[k]);
+            for (int k = 1; k < 4; k++) pt_add(acc, acc, sm[k]);
             partial[t0] = acc;
         }
         __syncthreads();
@@ -1379,7 +1379,7 @@ static constexpr int kBatchC = 8, kBatchW = 32;
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_decode_batch(const uint32_t *__restrict__ in, MsmPlan real, uint32_t ntotal, const uint32_t *__restrict__ coff, int M,
-                   Aff<F> *__restrict__ pts, uint32_t *__restrict__ digits, unsigned long long *err) {
+                   Aff<F> *__restrict__ pts, PtL *__restrict__ ptl, uint32_t *__restrict__ digits, unsigned long long *err) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= ntotal) return;
     int lo = 0, hi = M;                                   // call j with coff[j] <= i < coff[j + 1]
@@ -1391,15 +1391,19 @@ k_msm_decode_batch(const uint32_t *__restrict__ in, MsmPlan real, uint32_t ntota
     bool live = false;
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t *w = in + (size_t)i * Wire<F>::kMsmRecWords;
-    Aff<F> a;
-    const int st = decode_point<F>(a, w);
-    if (st != E_SUCCESS) {
-        atomicMin(&err[j], ((unsigned long long)(i - coff[j]) << 3) | (unsigned long long)st);
-    } else if (!is_inf(a)) {
-        pts[i] = a;
-        live = true;
-        decode_scalar(k, w + Wire<F>::kPointWords);
+    int st;
+    if (std::is_same<F, Fp>::value && ptl) {                  // uniform: limb records straight from the wire (G1)
+        st = decode_point_limbs(&ptl[i], w, live);
+    } else {
+        Aff<F> a;
+        st = decode_point_inl<F>(a, w);
+        if (st == E_SUCCESS && !is_inf(a)) {
+            pts[i] = a;
+            live = true;
+        }
     }
+    if (st != E_SUCCESS) atomicMin(&err[j], ((unsigned long long)(i - coff[j]) << 3) | (unsigned long long)st);
+    else if (live) decode_scalar(k, w + Wire<F>::kPointWords);
     int wi = 0;
     for_each_digit(k, real, [&](uint32_t g, uint32_t ng, bool nz) {
         const uint32_t v = g - (uint32_t)wi * real.B + 1u;                // bucket value 1..nb_w of the call's own plan
@@ -1410,13 +1414,11 @@ k_msm_decode_batch(const uint32_t *__restrict__ in, MsmPlan real, uint32_t ntota
 // WPU waves per (window, call) unit: 16 * WPU four-lane groups of 16 / WPU buckets each, wavefront tree,
 // and for WPU = 4 an LDS step across the block's waves.  Small batches take WPU = 4 (a chain of 8
 // running-sum additions instead of 32) while their 128 * M waves still fit the chip in one round.
-template <class F, int WPU>
+template <class F, int WPU, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256, 1)
 k_msm_reduce_batch(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, uint32_t units,
-                   Xyzz<F> *__restrict__ winout_) {
-    using T = typename AccumField<F>::T;
+                   Xyzz<F> *__restrict__ winout) {
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
-    Xyzz<T> *__restrict__ winout = reinterpret_cast<Xyzz<T> *>(winout_);
     claim_whole_simd();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
     const uint32_t unit = WPU == 4 ? blockIdx.x : blockIdx.x * 4u + (uint32_t)wave;
@@ -1442,11 +1444,70 @@ k_msm_reduce_batch(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restr
         __syncthreads();
         if (wave == 0 && lane < 4) {
             for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
-            if (lane == 0) winout[unit] = canon(C);
+            if (lane == 0) store_canon<F, T>(&winout[unit], C);
         }
     } else if (lane == 0) {
-        winout[unit] = canon(C);
+        store_canon<F, T>(&winout[unit], C);
     }
+}
+
+// The same over Fp2 with the 8-lane component-split operations (lanes.h: add8c, small_mul8c): the 4-lane form kept whole
+// Fp2 points replicated per lane (512 registers + 640-704 B of scratch per lane).  A wave holds 8 groups, so a unit is
+// 8 * WPU runs of 256 / (8 WPU) buckets.
+template <int WPU>
+__global__ void __launch_bounds__(256, 1)
+k_msm_reduce_batch8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict__ taskoff, uint32_t units,
+                     Xyzz<Fp2> *__restrict__ winout) {
+    claim_whole_simd();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 7, gb = lane & ~7, q = sl & 1;
+    const uint32_t unit = WPU == 4 ? blockIdx.x : blockIdx.x * 4u + (uint32_t)wave;
+    if (unit >= units) return;                                 // uniform in the wave (WPU = 4: in the block)
+    const PairProd8 prod(lane, sl, gb);
+    constexpr uint32_t S = kBatchBmax / (8u * WPU);
+    const uint32_t grp = (WPU == 4 ? (uint32_t)wave * 8u : 0u) + (uint32_t)(lane >> 3);
+    const uint32_t lo = grp * S, base = unit * kBatchBmax;
+    const Xyzz<FpI> inf = xyzz_inf<FpI>();
+    Xyzz<FpI> R = inf, Q = inf;
+    for (uint32_t v = lo + S; v > lo; v--) {
+        const uint32_t g = base + v - 1u;
+        const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+        if (t1 > t0) R = add8c(R, component_of(partial[t0], q), prod);      // multi-task buckets were folded into slot t0
+        Q = add8c(Q, R, prod);
+    }
+    Xyzz<FpI> C = add8c(Q, small_mul8c(R, lo, prod), prod);    // sum_{v in (lo, lo + S]} v * B_v
+    for (int off = 8; off < 64; off <<= 1) {
+        Xyzz<FpI> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 8) C = add8c(C, o, prod);
+    }
+    if (WPU == 4) {
+        __shared__ Xyzz<FpI> sm[4][2];              // [wave][component]
+        if (lane < 2) sm[wave][lane] = C;
+        __syncthreads();
+        if (wave == 0 && lane < 8) {
+            for (int k = 1; k < 4; k++) C = add8c(C, sm[k][q], prod);
+            if (lane < 2) store_component(&winout[unit], C, q);
+        }
+    } else if (lane < 2) {
+        store_component(&winout[unit], C, q);
+    }
+}
+static void launch_reduce_batch(hipStream_t s, uint32_t units, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff, Xyzz<Fp> *winout) {
+    const bool wide = units * 4u <= 1024u;       // one block per unit while 4 waves per unit fit one round of one wave per SIMD
+    const dim3 grid(wide ? units : (units + 3u) / 4u);
+    if (limb && wide) hipLaunchKernelGGL((k_msm_reduce_batch<Fp, 4, FpL>), grid, dim3(256), 0, s, partial, taskoff, units, winout);
+    else if (limb) hipLaunchKernelGGL((k_msm_reduce_batch<Fp, 1, FpL>), grid, dim3(256), 0, s, partial, taskoff, units, winout);
+    else if (wide) hipLaunchKernelGGL((k_msm_reduce_batch<Fp, 4>), grid, dim3(256), 0, s, partial, taskoff, units, winout);
+    else hipLaunchKernelGGL((k_msm_reduce_batch<Fp, 1>), grid, dim3(256), 0, s, partial, taskoff, units, winout);
+}
+static void launch_reduce_batch(hipStream_t s, uint32_t units, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff, Xyzz<Fp2> *winout) {
+    static const bool four = [] { const char *v = getenv("EIP2537_BATCH_G2_4LANE"); return v && atoi(v) != 0; }();      // A/B: the replicated 4-lane form of round 2
+    if (four) {
+        if (units * 4u <= 1024u) hipLaunchKernelGGL((k_msm_reduce_batch<Fp2, 4>), dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
+        else hipLaunchKernelGGL((k_msm_reduce_batch<Fp2, 1>), dim3((units + 3u) / 4u), dim3(256), 0, s, partial, taskoff, units, winout);
+        return;
+    }
+    if (units * 4u <= 1024u) hipLaunchKernelGGL(k_msm_reduce_batch8c<4>, dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
+    else hipLaunchKernelGGL(k_msm_reduce_batch8c<1>, dim3((units + 3u) / 4u), dim3(256), 0, s, partial, taskoff, units, winout);
 }
 
 // d_in: the M calls' records back to back in HBM; coff[0..M]: record offsets of the calls (host memory).
@@ -1471,7 +1532,10 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
     const uint32_t nbmax = pl.B;
     if (nbmax > 2u * kLdsWords) return E_MEMORY_ERROR;         // LDS histogram: 65536 packed counters
-    HIPCHK(e->pts.reserve(n * sizeof(Aff<F>)));
+    // G1: the whole batch pipeline in limb form (limb30.h), like the single-call plans of the same size
+    static const bool env_limb = [] { const char *v = getenv("EIP2537_LIMB_FORM"); return !v || atoi(v) != 0; }();
+    const bool limb_form = !ReduceCfg<F>::kFourLane && env_limb;
+    HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
     HIPCHK(e->digits.reserve((size_t)pl.W * n * 4));
@@ -1480,7 +1544,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
-    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * sizeof(Xyzz<F>)));
+    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve((size_t)units * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64 + (size_t)(M + 1) * 4 + (size_t)M * 8));
     HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + 2 * 65 * 4));
@@ -1515,12 +1579,14 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     {
         LastPlan lp{};
         if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");
+        else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2_l");
         else snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2<%s>", ReduceCfg<F>::kName);
         lp.c = pl.c; lp.windows = pl.W; lp.lanes = 2; lp.units = (uint32_t)n; lp.buckets = pl.NB;
         e->last_plan = lp;
     }
     HIPCHK(hipEventRecord(e->ev_start, s));
-    hipLaunchKernelGGL(k_msm_decode_batch<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, real, (uint32_t)n, d_coff, M, pts, digits, err);
+    PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
+    hipLaunchKernelGGL(k_msm_decode_batch<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, real, (uint32_t)n, d_coff, M, pts, ptl, digits, err);
     hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;
@@ -1535,14 +1601,11 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
     hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    launch_accum(s, task_blocks, true, pts, nullptr, entries, tasks, perm, totals, partial);      // two lanes per task
+    launch_accum(s, task_blocks, true, pts, ptl, entries, tasks, perm, totals, partial);          // two lanes per task
     HIPCHK(hipEventRecord(e->ev_b, s));
-    launch_fold_small(s, true, false, partial, taskoff, split_small, totals + 2);
-    hipLaunchKernelGGL(k_msm_fold_big<F>, dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2);
-    if (units * 4u <= 1024u)       // one block per unit while 4 waves per unit fit one round of one wave per SIMD
-        hipLaunchKernelGGL((k_msm_reduce_batch<F, 4>), dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
-    else
-        hipLaunchKernelGGL((k_msm_reduce_batch<F, 1>), dim3((units + 3u) / 4u), dim3(256), 0, s, partial, taskoff, units, winout);
+    launch_fold_small(s, true, limb_form, partial, taskoff, split_small, totals + 2);
+    launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
+    launch_reduce_batch(s, units, limb_form, partial, taskoff, winout);
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 

@@ -170,25 +170,26 @@ __device__ __forceinline__ void report_pair_error(unsigned long long *err, const
 __global__ void __launch_bounds__(256)
 k_pair_decode(const uint32_t *__restrict__ in, uint32_t k, PairPL *__restrict__ pl, PairQL *__restrict__ ql,
               uint8_t *__restrict__ flagP, uint8_t *__restrict__ flagQ, unsigned long long *err, CallMap cm) {
+    auto dmul = [](const Fp &x, const Fp &y) { return fp_mul_cols(x, y); };                 // inlined (no out-of-line call in this kernel)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x, i = t >> 1;
     if (i >= k) return;
     if ((t & 1u) == 0) {
         Aff<Fp> P;
-        const int st = decode_point<Fp>(P, in + (size_t)i * kPairWords);
+        const int st = decode_point_inl<Fp>(P, in + (size_t)i * kPairWords);
         if (st != E_SUCCESS) { report_pair_error(err, cm, i, (unsigned long long)st); P = Aff<Fp>{fp_zero(), fp_zero()}; }
-        store_limbs(pl[i].x, to_limbs(mul(P.x, Fp{{K_R390_MODP}})));
-        store_limbs(pl[i].y, to_limbs(mul(P.y, Fp{{K_R390_MODP}})));
-        store_limbs(pl[i].xs, to_limbs(mul(P.x, Fp{{K_R390_M3_MODP}})));
-        store_limbs(pl[i].ys, to_limbs(mul(P.y, Fp{{K_R390_2_MODP}})));
+        store_limbs(pl[i].x, to_limbs(dmul(P.x, Fp{{K_R390_MODP}})));
+        store_limbs(pl[i].y, to_limbs(dmul(P.y, Fp{{K_R390_MODP}})));
+        store_limbs(pl[i].xs, to_limbs(dmul(P.x, Fp{{K_R390_M3_MODP}})));
+        store_limbs(pl[i].ys, to_limbs(dmul(P.y, Fp{{K_R390_2_MODP}})));
         flagP[i] = (st == E_SUCCESS && !is_inf(P)) ? 1 : 0;
     } else {
         Aff<Fp2> Q;
-        const int st = decode_point<Fp2>(Q, in + (size_t)i * kPairWords + 32);
+        const int st = decode_point_inl<Fp2>(Q, in + (size_t)i * kPairWords + 32);
         if (st != E_SUCCESS) { report_pair_error(err, cm, i, 8ull | (unsigned long long)st); Q = Aff<Fp2>{fp2_zero(), fp2_zero()}; }
-        store_limbs(ql[i].c[0][0], to_limbs(mul(Q.x.c0, Fp{{K_R390_MODP}})));
-        store_limbs(ql[i].c[1][0], to_limbs(mul(Q.x.c1, Fp{{K_R390_MODP}})));
-        store_limbs(ql[i].c[0][1], to_limbs(mul(Q.y.c0, Fp{{K_R390_MODP}})));
-        store_limbs(ql[i].c[1][1], to_limbs(mul(Q.y.c1, Fp{{K_R390_MODP}})));
+        store_limbs(ql[i].c[0][0], to_limbs(dmul(Q.x.c0, Fp{{K_R390_MODP}})));
+        store_limbs(ql[i].c[1][0], to_limbs(dmul(Q.x.c1, Fp{{K_R390_MODP}})));
+        store_limbs(ql[i].c[0][1], to_limbs(dmul(Q.y.c0, Fp{{K_R390_MODP}})));
+        store_limbs(ql[i].c[1][1], to_limbs(dmul(Q.y.c1, Fp{{K_R390_MODP}})));
         flagQ[i] = (st == E_SUCCESS && !is_inf(Q)) ? 1 : 0;
     }
 }
@@ -377,17 +378,23 @@ k_pair_fold(const LineL *__restrict__ lines, const PairPL *__restrict__ pl, uint
     for (uint32_t li = G; li < count; li += nq) {               // uniform within the quad
         const uint32_t i = base + li;
         const LineL *rec = &lines[(size_t)s * k + i];
-        const auto a0 = load_lv<LineK::A0>(rec->v[x.q][0]);
+        // the three coefficients are loaded and scaled one after the other (the empty asm keeps the loads from being hoisted
+        // together: five limb strings in flight at once cost the loop more spills at two waves per SIMD)
         const auto r1 = load_lv<LineK::A1A>(rec->v[x.q][1]);
-        const auto r4 = load_lv<LineK::A4A>(rec->v[x.q][2]);
-        const auto xs = load_lv<1>(pl[i].xs), ys = load_lv<1>(pl[i].ys);
+        const auto xs = load_lv<1>(pl[i].xs);
         // a1 = X^2 xs (tangent) or (2 theta) xs (chord); component 0 of X^2 = (x0 + x1)(x0 - x1), component 1 = 2 x0 x1
         const auto rp = x.swap(r1);
         const auto sq = mulB(x.pick_q(addB(r1, rp), dblB(r1)), x.pick_q(subB(r1, rp), rp));
         LV<max2(decltype(sq)::kK, LineK::A1A), 1> pre;
 #pragma unroll
         for (int t = 0; t < 13; t++) pre.l[0].l[t] = pick2(is_add, r1.l[0].l[t], sq.l[0].l[t]);      // by value: an lvalue conditional would pin both in scratch
-        const auto a1 = mulB(pre, xs), a4 = mulB(r4, ys);
+        const auto a1 = mulB(pre, xs);
+        asm volatile("" ::: "memory");
+        const auto r4 = load_lv<LineK::A4A>(rec->v[x.q][2]);
+        const auto ys = load_lv<1>(pl[i].ys);
+        const auto a4 = mulB(r4, ys);
+        asm volatile("" ::: "memory");
+        const auto a0 = load_lv<LineK::A0>(rec->v[x.q][0]);
         if (!have) { f = quad_seed_line(x, a0, a1, a4); have = true; }
         else quad_fold_line(x, f, a0, a1, a4);
     }
