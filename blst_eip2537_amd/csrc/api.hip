@@ -382,7 +382,9 @@ template <class F> static int msm_dev_abi(byte *out, const void *d_in, size_t n,
 // This is a size rule inside a working engine, not a fallback: without a usable HIP device these
 // calls still fail loudly (the device is selected first), and every size above the crossover has no
 // host path at all.  eip2537_hip_set_route() pins the route for tests.
-static constexpr size_t kHostMaxG1 = 16, kHostMaxG2 = 8, kHostMaxPairs = 4;
+// round 3 (profiles/r03_small_calls.txt): the pairing pipeline's fixed latency fell from 1.9 to 0.8 ms, so the host route now
+// ends at 2 pairs (0.67 ms; 3 pairs: 0.91 on the host against 0.85), and at 6 G2 records (8: 0.67 against 0.63)
+static constexpr size_t kHostMaxG1 = 16, kHostMaxG2 = 6, kHostMaxPairs = 2;
 static constexpr size_t kHostRouteTestMax = 64;        // route 1 ("host whenever allowed") still refuses more
 template <class F> struct HostMax { static constexpr size_t kUnits = kHostMaxG1; };
 template <> struct HostMax<Fp2> { static constexpr size_t kUnits = kHostMaxG2; };
@@ -726,7 +728,18 @@ static int pairing_coalesced(byte *out, const byte *in, size_t k) {
     req.n = k;
     coalesce(req, (size_t)kPairBatchMaxCalls, (size_t)2048, [](std::vector<PairReq *> &batch) { run_pair_batch(batch); });
     if (req.rc) return req.rc;
-    pairing_finish(out, req.have_ml ? req.ml : miller_product_from_steps(req.L));
+    if (req.have_ml) { pairing_finish(out, req.ml); return E_SUCCESS; }
+#if defined(EIP_HAVE_IFMA)
+    if (host_ifma_enabled()) {                                   // the 68 per-step products by AVX-512 IFMA (ifma.h)
+        int nsq[kPairSteps];
+        uint64_t zbits = K_Z_ABS;
+        int si = 0;
+        for (int bit = 62; bit >= 0; bit--) { nsq[si++] = 1; if ((zbits >> bit) & 1ull) nsq[si++] = 0; }
+        pairing_finish(out, conj(ifma::horner_groups_ifma(req.L, nsq, kPairSteps)));
+        return E_SUCCESS;
+    }
+#endif
+    pairing_finish(out, miller_product_from_steps(req.L));
     return E_SUCCESS;
 }
 static int pairing_host_abi(byte *out, const byte *in, size_t in_len) {

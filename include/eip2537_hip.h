@@ -83,16 +83,16 @@ int eip2537_hip_gen_g2_msm_input(uint8_t *out, size_t n, const uint8_t a_le[32],
 int eip2537_hip_gen_pairing_input(uint8_t *out, size_t k, const uint8_t a0[32], const uint8_t a1[32],
                                   const uint8_t b0[32], const uint8_t b1[32], uint64_t start);
 
-/* Concurrent small calls (multiexp above the host crossover and up to 512 records, pairing checks of 5..64 pairs, host input) are
+/* Concurrent small calls (multiexp above the host crossover and up to 512 records, pairing checks of 3..64 pairs, host input) are
  * coalesced: callers that arrive while the engine is busy are served together by ONE device pipeline over
  * their concatenated records, each with its own result and error code ($EIP2537_HIP_COALESCE=0 disables).  Counters since load: device
  * pipelines run for such calls, calls served, and the largest number of calls in one pipeline. */
 void eip2537_hip_coalesce_stats(uint64_t *pipelines, uint64_t *calls, uint64_t *largest_batch);
 
 /* Testing hook for the small-call crossover: the reference-ABI multiexp / pairing calls run the
- * library's own host code up to a measured size (G1 MSM 16 records, G2 MSM 8 -- the reference itself
- * forwards n == 1 to the mul precompile, src/eip2537.c:550-552 --, pairing 4 pairs:
- * profiles/r02_small_calls.txt) and the GPU above it.  route = 0: always the GPU; 1: the host code up to 64 units; -1: the default rule. */
+ * library's own host code up to a measured size (G1 MSM 16 records, G2 MSM 6 -- the reference itself
+ * forwards n == 1 to the mul precompile, src/eip2537.c:550-552 --, pairing 2 pairs:
+ * profiles/r03_small_calls.txt) and the GPU above it.  route = 0: always the GPU; 1: the host code up to 64 units; -1: the default rule. */
 int eip2537_hip_set_route(int route);
 
 /* Testing hook: force the Pippenger window width (4..16); 0 restores the cost model. */

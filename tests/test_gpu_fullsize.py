@@ -160,10 +160,11 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
 
 
 def test_pairing_all_walk_kernels_ragged_sizes(X, clib):
-    """k <= 2048 runs the 16-lane line walk, k <= 5120 the 8-lane one, larger batches the 4-lane one;
-    ragged sizes around both switches, each closed to the identity and broken by one, and an error
-    in the last (partial) group."""
-    for k in (2047, 2049, 2100, 5119, 5121, 5203):
+    """Ragged sizes around every switch of the pairing pipeline: up to 64 pairs one line-product block per step (a quad per
+    line), up to 448 pairs one line per quad over 2..7 blocks, beyond that quads fold several lines; walk + membership
+    waves claim whole SIMDs while they fit the chip (k / 8 + k / 16 <= 1024, i.e. up to 5461 pairs).  Each size closed to
+    the identity and broken by one, and an error in the last (partial) group."""
+    for k in (63, 65, 447, 449, 2100, 5461, 5463):
         good, bad = _pairing_batch(X, k, 0), _pairing_batch(X, k, 1)
         assert call_x(X.pairing, good) == (0, bytes(31) + b"\x01"), k
         assert call_x(X.pairing, bad) == (0, bytes(32)), k

@@ -2,7 +2,7 @@
 """Small-call crossover table: time of one reference-ABI call through the product (default
 route: the library's host code below the crossover, the GPU above it; also with the route pinned) against
 the 1-core CPU port of the reference path (oracle/), for the sizes the EVM actually sends.  Run on the GPU
-box; output goes to profiles/r02_small_calls.txt."""
+box; output goes to profiles/rNN_small_calls.txt."""
 import os
 import statistics
 import sys
