@@ -364,13 +364,15 @@ __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
             uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts,
-            uint32_t *__restrict__ lenhist, uint32_t gshift) {
+            uint32_t *__restrict__ lenhist, uint32_t gshift, uint32_t split_g) {
     // also the histogram of task length classes ceil(len / 2^gshift) in [1, 64] for the sort below (a
-    // separate pass over the task array before: 0.03 ms at 2^20)
-    __shared__ uint32_t h[65];
-    if (threadIdx.x < 65) h[threadIdx.x] = 0;
+    // separate pass over the task array before: 0.03 ms at 2^20); buckets from split_g on are counted as
+    // a second set (their tasks are ordered and accumulated on their own: two-level reduce)
+    __shared__ uint32_t h[130];
+    if (threadIdx.x < 130) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t hs = g >= split_g ? 65u : 0u;
     const uint32_t cnt = g < NB ? counts[g] : 0u;
     if (cnt) {
         const uint32_t t0 = taskoff[g], off = offsets[g];
@@ -382,11 +384,11 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
         const uint32_t full = cnt >> lshift, rest = cnt & (L - 1u);
         for (uint32_t j = 0; j < full; j++) tasks[t0 + j] = Task{off + (j << lshift), L};
         if (rest) tasks[t0 + full] = Task{off + (full << lshift), rest};
-        if (full) atomicAdd(&h[(L + gm) >> gshift], full);
-        if (rest) atomicAdd(&h[(rest + gm) >> gshift], 1u);
+        if (full) atomicAdd(&h[hs + ((L + gm) >> gshift)], full);
+        if (rest) atomicAdd(&h[hs + ((rest + gm) >> gshift)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 65 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < 130 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
 }
 
 
@@ -395,28 +397,39 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
 // Counting sort on the length class ceil(len / (L/64)) in [1, 64]: per-block LDS histogram -> 64 global counters -> a one-wave
 // scan -> per-block range reservation -> permutation.
 __global__ void __launch_bounds__(64)
-k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ lenoff) {
-    // lane i owns length 64 - i (longest first); exclusive prefix over lanes
+k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges) {
+    // lane i owns length 64 - i (longest first); exclusive prefix over lanes, the second set behind the first.
+    // ranges: [0, n0) = slots of the first set, [n0, n0 + n1) = slots of the second
     const uint32_t i = threadIdx.x;
-    uint32_t v = lenhist[64 - i], incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(incl, off, 64);
-        if ((int)i >= off) incl += o;
+    uint32_t base = 0;
+    for (uint32_t set = 0; set < 2; set++) {
+        uint32_t v = lenhist[set * 65u + 64 - i], incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(incl, off, 64);
+            if ((int)i >= off) incl += o;
+        }
+        lenoff[set * 65u + 64 - i] = base + incl - v;
+        if (i == 0) lenoff[set * 65u] = 0;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (i == 0) { ranges[2 * set] = base; ranges[2 * set + 1] = base + total; }
+        base += total;
     }
-    lenoff[64 - i] = incl - v;
-    if (i == 0) lenoff[0] = 0;
 }
 __global__ void __launch_bounds__(256)
 k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenoff,
-                uint32_t *__restrict__ perm, uint32_t gshift) {
-    __shared__ uint32_t h[65], base[65];
-    if (threadIdx.x < 65) h[threadIdx.x] = 0;
+                uint32_t *__restrict__ perm, uint32_t gshift, const uint32_t *__restrict__ taskoff, uint32_t split_g) {
+    __shared__ uint32_t h[130], base[130];
+    if (threadIdx.x < 130) h[threadIdx.x] = 0;
     __syncthreads();
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     uint32_t len = 0, local = 0;
-    if (t < totals[1]) { len = (tasks[t].len + (1u << gshift) - 1u) >> gshift; local = atomicAdd(&h[len], 1u); }
+    const uint32_t t_split = split_g == 0xffffffffu ? 0xffffffffu : taskoff[split_g];     // task ids follow the bucket order
+    if (t < totals[1]) {
+        len = ((tasks[t].len + (1u << gshift) - 1u) >> gshift) + (t >= t_split ? 65u : 0u);
+        local = atomicAdd(&h[len], 1u);
+    }
     __syncthreads();
-    if (threadIdx.x < 65 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&lenoff[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < 130 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&lenoff[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
     if (len) perm[base[len] + local] = t;
 }
@@ -599,10 +612,12 @@ k_msm_accum(const Aff<F> *__restrict__ pts_, const uint32_t *__restrict__ entrie
 //   x < 8, y < 4, zz < 2, zzz < 2;   inside: P < 10, R < 6, every product of a b < 630.
 __global__ void __launch_bounds__(256)
 k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
-              const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp> *__restrict__ partial_) {
+              const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp> *__restrict__ partial_,
+              const uint32_t *__restrict__ range) {
     Xyzz<FpL> *__restrict__ partial = reinterpret_cast<Xyzz<FpL> *>(partial_);     // read by the <Fp, FpL> fold and reduce kernels
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (slot >= totals[1]) return;
+    // range: the slots [range[0], range[1]) of the task order (two-level reduce: the top window's upper half first); null: all
+    const uint32_t slot = (range ? range[0] : 0u) + blockIdx.x * 256u + threadIdx.x;
+    if (slot >= (range ? range[1] : totals[1])) return;
     const uint32_t t = perm[slot];
     const Task tk = tasks[t];
     AccL acc;
@@ -746,11 +761,13 @@ __device__ __forceinline__ void pt_dbl(Xyzz<FpL> &r, const Xyzz<FpL> &a) { r = d
 template <class F, class T = typename AccumField<F>::T>    // T: the form the accumulate kernel wrote the partials in (G1: FpI or FpL)
 __global__ void __launch_bounds__(256)
 k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
-                 const uint32_t *__restrict__ split_counts) {
+                 const uint32_t *__restrict__ split_counts, uint32_t g_lo = 0u, uint32_t g_hi = 0xffffffffu) {
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
     for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < n; h += gridDim.x * 256u) {
-        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        const uint32_t g = list[h];
+        if (g < g_lo || g >= g_hi) continue;                   // two-level reduce: the buckets of one accumulate launch only
+        const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
         Xyzz<T> acc = partial[t0];
         for (uint32_t t = t0 + 1; t < t1; t++) {
             Xyzz<T> pt = partial[t];
@@ -763,13 +780,15 @@ k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ ta
 template <class F, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256)
 k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
-               const uint32_t *__restrict__ split_counts) {
+               const uint32_t *__restrict__ split_counts, uint32_t g_lo = 0u, uint32_t g_hi = 0xffffffffu) {
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     __shared__ Xyzz<T> sm[4];
     const uint32_t nh = split_counts[1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        const uint32_t g = list[h];
+        if (g < g_lo || g >= g_hi) continue;                   // uniform in the block
+        const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
         Xyzz<T> acc = xyzz_inf<T>();
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
             Xyzz<T> pt = partial[t];
@@ -1027,26 +1046,25 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
 // kRcChain buckets plus a short wavefront tree, like the accumulate.  What is left per window are weighted
 // sums over 128 + 256 entries: k_msm_reduce_rc, the 4-lane running-sum kernel of the small plans on 32 blocks.
 // The host's Horner takes R_w = sum hi Row_hi and C_w = sum (lo + 1) Col_lo as two 8-bit half-windows.
+// The unsigned top window (2^16 values) is two half-windows of 2^15 buckets as far as bucket ids go (BT = 2 B), so the
+// kernels see W + 1 "virtual windows" of B buckets each; the upper half TB of the top window (virtual window W) only adds
+// 128 to its row weights.  16 virtual windows are exactly 1 024 waves of 16-bucket chains -- one per SIMD --, and TB's sums
+// (k_msm_rowcol on a second stream) hide behind the accumulate of the other windows: TB's tasks are accumulated first.
 static constexpr uint32_t kRcCols = 256, kRcChain = 16;
-__host__ __device__ inline uint32_t rc_rows(const MsmPlan &pl, int w) { return (w == pl.W - 1 ? pl.BT : pl.B) / kRcCols; }
-__host__ __device__ inline uint32_t rc_base(const MsmPlan &pl, int w) { return (uint32_t)w * (pl.B / kRcCols + kRcCols); }   // entries before window w
+static constexpr uint32_t kRcRows = 128, kRcPerWindow = kRcRows + kRcCols;                 // B = 32 768 = 128 x 256
 __global__ void __launch_bounds__(256)
-k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, Xyzz<FpL> *__restrict__ rc) {
+k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, uint32_t B, uint32_t w0, Xyzz<FpL> *__restrict__ rc) {
     const Xyzz<FpL> *__restrict__ partial = reinterpret_cast<const Xyzz<FpL> *>(partial_);
-    const uint32_t lanes_w = 2u * pl.B / kRcChain;                     // lanes of a signed window: rows + columns
+    const uint32_t lanes_w = 2u * B / kRcChain;                        // lanes of a virtual window: rows + columns
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const int w = (int)min(t / lanes_w, (uint32_t)(pl.W - 1));
-    const uint32_t local = t - (uint32_t)w * lanes_w, nr = rc_rows(pl, w);
-    if (local >= 2u * nr * kRcCols / kRcChain) return;                 // whole waves
-    const uint32_t row_lanes = nr * (kRcCols / kRcChain);
+    const uint32_t w = w0 + t / lanes_w, local = t % lanes_w;
+    const uint32_t row_lanes = kRcRows * (kRcCols / kRcChain);
     const bool is_row = local < row_lanes;                             // uniform in the wave
-    const uint32_t lj = is_row ? kRcCols / kRcChain : nr / kRcChain;  // lanes per job
+    const uint32_t lj = is_row ? kRcCols / kRcChain : kRcRows / kRcChain;      // lanes per job: 16 | 8
     const uint32_t l2 = is_row ? local : local - row_lanes, job = l2 / lj, sub = l2 % lj;
     // row job: buckets 256 job + (sub + i lj);   column job: buckets 256 (sub + i lj) + job
-    const uint32_t first = (uint32_t)w * pl.B + (is_row ? job * kRcCols + sub : sub * kRcCols + job);
+    const uint32_t first = w * B + (is_row ? job * kRcCols + sub : sub * kRcCols + job);
     const uint32_t step = is_row ? lj : lj * kRcCols;
-    // the next bucket's sum is loaded while the current addition runs (one wave per SIMD: nothing else hides the two
-    // dependent loads, taskoff then the 208-byte point)
     auto fetch = [&](uint32_t i, Xyzz<FpL> &pt) {
         const uint32_t g = first + i * step;
         const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
@@ -1063,29 +1081,30 @@ k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__
         acc = add(acc, cur);
     }
     const int lane = threadIdx.x & 63;
-    for (uint32_t off = lj >> 1; off >= 1; off >>= 1) {                 // lj <= 32: the job's lanes are one aligned run of the wave
+    for (uint32_t off = lj >> 1; off >= 1; off >>= 1) {                 // the job's lanes are one aligned run of the wave
         const Xyzz<FpL> o = shfl_from(acc, (lane + (int)off) & 63);
         if (sub < off) acc = add(acc, o);
     }
-    if (sub == 0) rc[rc_base(pl, w) + (is_row ? job : nr + job)] = acc;
+    if (sub == 0) rc[w * kRcPerWindow + (is_row ? job : kRcRows + job)] = acc;
 }
-// grid = 2 W blocks: block 2 w sums hi Row_hi (weights from 0), block 2 w + 1 sums (lo + 1) Col_lo; 64 four-lane
-// groups per block, each a run of S entries:  sum_{e in [a, b)} (e + fw) X_e = Q + a R  with the running sums
+// grid = 2 (W + 1) blocks: block 2 w sums (hi + row_weight0) Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of virtual window w; 64
+// four-lane groups per block, each a run of S entries:  sum_{e in [a, b)} (e + fw) X_e = Q + (a + offset) R  with the running sums
 // taken from the top, Q skipping its last addition when the weights start at 0.
 __global__ void __launch_bounds__(256, 1)
-k_msm_reduce_rc(const Xyzz<FpL> *__restrict__ rc, MsmPlan pl, Xyzz<Fp> *__restrict__ winout) {
+k_msm_reduce_rc(const Xyzz<FpL> *__restrict__ rc, int W, Xyzz<Fp> *__restrict__ winout) {
     const int w = blockIdx.x >> 1, kind = blockIdx.x & 1;
     claim_whole_simd();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
-    const uint32_t nr = rc_rows(pl, w), n = kind ? kRcCols : nr, fw = kind ? 1u : 0u;
-    const Xyzz<FpL> *ent = rc + rc_base(pl, w) + (kind ? nr : 0u);
+    const uint32_t n = kind ? kRcCols : kRcRows, fw = kind ? 1u : 0u;
+    const uint32_t weight0 = (!kind && w == W) ? kRcRows : 0u;          // the top window's upper half: rows 128 .. 255
+    const Xyzz<FpL> *ent = rc + (size_t)w * kRcPerWindow + (kind ? kRcRows : 0u);
     const uint32_t S = n / 64u, a = (uint32_t)(threadIdx.x >> 2) * S;   // 64 groups
     Xyzz<FpL> R = xyzz_inf<FpL>(), Q = xyzz_inf<FpL>();
     for (uint32_t e = a + S; e > a; e--) {
         R = add4(R, ent[e - 1], r, gb);
         if (e - 1 > a || fw) Q = add4(Q, R, r, gb);
     }
-    Xyzz<FpL> C = add4(Q, small_mul4(R, a, r, gb), r, gb);
+    Xyzz<FpL> C = add4(Q, small_mul4(R, a + weight0, r, gb), r, gb);
     for (int off = 4; off < 64; off <<= 1) {
         Xyzz<FpL> o = shfl_from(C, (lane + off) & 63);
         if ((lane & (2 * off - 1)) < 4) C = add4(C, o, r, gb);
@@ -1106,7 +1125,7 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, 
     else if (chain_bound)
         hipLaunchKernelGGL(k_msm_accum2<Fp>, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
     else if (ptl)
-        hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial);
+        hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial, (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(k_msm_accum<Fp>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
@@ -1145,11 +1164,38 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const 
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
-static void launch_rowcol(hipStream_t s, uint32_t blocks, const Xyzz<Fp> *partial, const uint32_t *taskoff, const MsmPlan &pl, Xyzz<FpL> *rc, Xyzz<Fp> *winout) {
-    hipLaunchKernelGGL(k_msm_rowcol, dim3(blocks), dim3(256), 0, s, partial, taskoff, pl, rc);
-    hipLaunchKernelGGL(k_msm_reduce_rc, dim3(2u * (uint32_t)pl.W), dim3(256), 0, s, rc, pl, winout);
+// Two-level reduce of a G1 c = 16 plan (k_msm_rowcol / k_msm_reduce_rc): the top window's upper half TB is accumulated, folded and
+// summed on stream3 beside the accumulate of everything else (TB's tasks finish long before the rest: 1 / 17 of the work); the
+// row / column launch on the critical path then is the 16 other virtual windows = exactly 1 024 waves.
+static int launch_two_level(Engine *e, const MsmPlan &pl, size_t n, uint32_t lshift, uint32_t task_blocks, uint32_t red_blocks, uint32_t split_g,
+                            const PtL *ptl, const uint32_t *entries, const Task *tasks, const uint32_t *perm, const uint32_t *totals,
+                            const uint32_t *ranges, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *split_small,
+                            const uint32_t *split_big, Xyzz<Fp> *winout) {
+    hipStream_t s = e->stream;
+    auto *rc = reinterpret_cast<Xyzz<FpL> *>(e->slice_base.p);
+    const uint32_t tb_blocks = (pl.B + (uint32_t)(n >> lshift) + 1u + 255u) / 256u;      // at most B buckets + n / L full tasks
+    const uint32_t unit_blocks = (2u * pl.B / kRcChain) / 256u;                          // blocks of one virtual window in k_msm_rowcol
+    // stream3, beside the main accumulate (a launch of TB's ~770 waves alone would be a latency chain on an empty chip: 0.25 ms lost)
+    hipStream_t s3 = e->stream3;
+    HIPCHK(hipEventRecord(e->ev_j3, s));
+    HIPCHK(hipStreamWaitEvent(s3, e->ev_j3, 0));
+    hipLaunchKernelGGL(k_msm_accum_l, dim3(tb_blocks), dim3(256), 0, s3, ptl, entries, tasks, perm, totals, partial, ranges + 2);
+    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s3, partial, taskoff, split_small, totals + 2, split_g, 0xffffffffu);
+    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s3, partial, taskoff, split_big, totals + 2, split_g, 0xffffffffu);
+    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks), dim3(256), 0, s3, (const Xyzz<Fp> *)partial, taskoff, pl.B, (uint32_t)pl.W, rc);
+    HIPCHK(hipEventRecord(e->ev_j2, s3));
+    hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial, ranges);
+    HIPCHK(hipEventRecord(e->ev_b, s));
+    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2, 0u, split_g);
+    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2, 0u, split_g);
+    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks * (uint32_t)pl.W), dim3(256), 0, s, (const Xyzz<Fp> *)partial, taskoff, pl.B, 0u, rc);      // 16 units: 1 024 waves
+    HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
+    hipLaunchKernelGGL(k_msm_reduce_rc, dim3(red_blocks), dim3(256), 0, s, (const Xyzz<FpL> *)rc, pl.W, winout);
+    return E_SUCCESS;
 }
-static void launch_rowcol(hipStream_t, uint32_t, const Xyzz<Fp2> *, const uint32_t *, const MsmPlan &, Xyzz<FpL> *, Xyzz<Fp2> *) {}
+static int launch_two_level(Engine *, const MsmPlan &, size_t, uint32_t, uint32_t, uint32_t, uint32_t, const PtL *, const uint32_t *, const Task *,
+                            const uint32_t *, const uint32_t *, const uint32_t *, Xyzz<Fp2> *, const uint32_t *, const uint32_t *, const uint32_t *,
+                            Xyzz<Fp2> *) { return E_MEMORY_ERROR; }      // (never selected for G2)
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; static constexpr const char *kName = "eip::Fp"; };
@@ -1209,16 +1255,17 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernels.
     static const bool env_limb = [] { const char *v = getenv("EIP2537_LIMB_FORM"); return !v || atoi(v) != 0; }();
     const bool limb_form = !ReduceCfg<F>::kFourLane && env_limb && (pl.c > 13 ? !four : four);     // G1: (one lane, reduce1) or (two lanes, reduce4)
-    // G1, c = 16: the two-level reduce (row / column sums, then 2 W small weighted sums); EIP2537_REDUCE_RC=0: the one-lane chain
-    // Measured at 2^20 (profiles/r03_two_level_reduce.txt): row / column sums 0.60 ms + weighted sums 0.24 ms against 0.89 ms
-    // for the one-lane chain -- no gain, because 17 half-window units of buckets (the unsigned top window counts twice)
-    // make 1 088 waves of 16-bucket chains for 1 024 SIMDs, and the 64 SIMDs that get two waves set the time (with the
-    // last unit dropped: 0.37 ms, 3.43 instead of 3.80 ms per MSM).  Off by default; EIP2537_REDUCE_RC=1 selects it.
-    static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return v && atoi(v) != 0; }();
-    const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B % (kRcCols * 64u) == 0 && pl.BT % (kRcCols * 64u) == 0;
-    if (two_level) red_blocks = 2u * (uint32_t)pl.W;
+    // G1, c = 16: the two-level reduce (row / column sums k_msm_rowcol, then 2 (W + 1) small weighted sums k_msm_reduce_rc);
+    // EIP2537_REDUCE_RC=0: the one-lane chain k_msm_reduce1.  Round 3, first form (profiles/r03_two_level_reduce.txt): all 17
+    // half-window units in one launch are 1 088 waves for 1 024 SIMDs -- 0.60 + 0.24 ms, no gain over the chain's 0.89 ms.  Final
+    // form: the upper half of the top window is accumulated FIRST and its sums run on a second stream behind the accumulate of the
+    // rest, so that the launch on the critical path is exactly 1 024 waves (0.37 ms).
+    static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return !v || atoi(v) != 0; }();
+    const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B == kRcRows * kRcCols && pl.BT == 2u * pl.B;
+    if (two_level) red_blocks = 2u * (uint32_t)(pl.W + 1);
     const size_t nwin_out = red_blocks;
-    const size_t rc_bytes = two_level ? (size_t)(rc_base(pl, pl.W - 1) + rc_rows(pl, pl.W - 1) + kRcCols) * sizeof(Xyzz<FpL>) : 0;
+    const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
+    const uint32_t split_g = two_level ? (uint32_t)pl.W * pl.B : 0xffffffffu;      // first bucket of the top window's upper half
     HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
@@ -1233,7 +1280,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + 2 * 65 * 4));     // scan block totals + task-length histogram/offsets
+    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
@@ -1301,32 +1348,32 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
+    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
-    HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));
+    HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2, lenhist, gshift);
+                       split_small, split_big, totals + 2, lenhist, gshift, split_g);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
-    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
+    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
     HIPCHK(hipEventRecord(e->ev_a, s));
-    // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
-    launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
-    HIPCHK(hipEventRecord(e->ev_b, s));
-    launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
-    launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
     if (two_level) {
-        auto *rc = reinterpret_cast<Xyzz<FpL> *>(e->slice_base.p);
-        const uint32_t rc_lanes = (uint32_t)(pl.W - 1) * (2u * pl.B / kRcChain) + 2u * pl.BT / kRcChain;
-        static const uint32_t env_cut = [] { const char *v = getenv("EIP2537_RC_CUT"); return v ? (uint32_t)atoi(v) : 0u; }();   // timing experiment: drop blocks (wrong result)
-        launch_rowcol(s, (rc_lanes + 255u) / 256u - env_cut, partial, taskoff, pl, rc, winout);
-    } else
+        int st2 = launch_two_level(e, pl, n, lshift, task_blocks, red_blocks, split_g, ptl, entries, tasks, perm, totals, ranges, partial, taskoff,
+                                   split_small, split_big, winout);
+        if (st2) return st2;
+    } else {
+        // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
+        launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
+        HIPCHK(hipEventRecord(e->ev_b, s));
+        launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
+        launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
         launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
+    }
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
@@ -1347,7 +1394,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // Horner over windows on the host (W * c doublings + a handful of additions)
     Xyzz<F> acc = xyzz_inf<F>();
     if (two_level) {
-        // window sum = 256 R_w + C_w: two half-windows of 8 bits each
+        // window sum = 256 R_w + C_w: two half-windows of 8 bits each; the top window is its two halves added
+        hw[2 * (size_t)(pl.W - 1)] = add(hw[2 * (size_t)(pl.W - 1)], hw[2 * (size_t)pl.W]);
+        hw[2 * (size_t)(pl.W - 1) + 1] = add(hw[2 * (size_t)(pl.W - 1) + 1], hw[2 * (size_t)pl.W + 1]);
         for (int w = pl.W - 1; w >= 0; w--)
             for (int h = 0; h < 2; h++) {
                 for (int d = 0; d < pl.c / 2; d++) acc = dbl(acc);
@@ -1547,7 +1596,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve((size_t)units * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64 + (size_t)(M + 1) * 4 + (size_t)M * 8));
-    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + 2 * 65 * 4));
+    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4));
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
@@ -1573,7 +1622,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 65;
+    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     {
@@ -1590,16 +1639,16 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;
-    HIPCHK(hipMemsetAsync(lenhist, 0, 2 * 65 * 4, s));
+    HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2, lenhist, gshift);
+                       split_small, split_big, totals + 2, lenhist, gshift, 0xffffffffu);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff);
-    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift);
+    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, 0xffffffffu);
     HIPCHK(hipEventRecord(e->ev_a, s));
     launch_accum(s, task_blocks, true, pts, ptl, entries, tasks, perm, totals, partial);          // two lanes per task
     HIPCHK(hipEventRecord(e->ev_b, s));

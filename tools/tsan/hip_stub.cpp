@@ -21,6 +21,8 @@ hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
