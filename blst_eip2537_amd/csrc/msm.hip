@@ -360,6 +360,151 @@ k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices,
     }
 }
 
+// ---- partitioned counting sort (c = 16 plans) ------------------------------------------------------------
+// The scatter above places every entry directly: 4-byte stores to random positions of a 4 MB window region, 0.28 ms and
+// 530 MB written for 67 MB of entries at 2^20 even in four bucket-range passes, on top of per-bucket slice histograms of
+// 67 + 134 MB.  Round 3: two passes that only ever write RUNS.  Bucket b = 128 part + fine.
+//   k_sort_coarse_hist     [slice x window]  LDS histogram over the <= 512 partitions of the window
+//   k_sort_coarse_scan     [window]          exclusive prefix over (partition, slice) in place, window totals
+//   k_sort_window_bases    [1 block]         exclusive prefix of the window totals
+//   k_sort_coarse_scatter  [slice x window]  ranks by LDS atomics, the slice's entries staged in LDS in partition order and
+//                                            written out as one run per partition: (record << 8 | sign << 7 | fine)
+//   k_sort_fine            [partition x window]  the partition's run (~4 096 entries) counted and ranked over its 128
+//                                            buckets in LDS, written out in bucket order; per-bucket counts
+// Entry positions equal the exclusive scan of the counts in bucket order, so the scan / task kernels run unchanged.
+static constexpr uint32_t kFineBits = 7, kFine = 1u << kFineBits, kMaxParts = 512;
+__global__ void __launch_bounds__(1024)
+k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ chist) {
+    __shared__ uint32_t h[kMaxParts];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
+    if (threadIdx.x < kMaxParts) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
+        const uint32_t v = digits[(size_t)w * pl.n + i];
+        if (v) atomicAdd(&h[((v >> 1) - 1u) >> kFineBits], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < parts) chist[((size_t)w * kMaxParts + threadIdx.x) * nslices + slice] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(1024)
+k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ wtotal) {
+    __shared__ uint32_t sm[1024];
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
+    const uint32_t E = parts * nslices, chunk = (E + 1023u) / 1024u;
+    uint32_t *row = chist + (size_t)w * kMaxParts * nslices;
+    const uint32_t a = min(t * chunk, E), b = min(a + chunk, E);
+    uint32_t sum = 0;
+    for (uint32_t k = a; k < b; k++) sum += row[k];
+    sm[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = t >= off ? sm[t - off] : 0u;
+        __syncthreads();
+        sm[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sm[t] - sum;                                  // exclusive
+    for (uint32_t k = a; k < b; k++) { const uint32_t v = row[k]; row[k] = run; run += v; }
+    if (t == 1023u) wtotal[w] = sm[t];
+}
+__global__ void __launch_bounds__(64)
+k_sort_window_bases(const uint32_t *__restrict__ wtotal, int W, uint32_t *__restrict__ wbase) {
+    const uint32_t i = threadIdx.x;
+    uint32_t v = (int)i < W ? wtotal[i] : 0u, incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)i >= off) incl += o;
+    }
+    if ((int)i <= W) wbase[i] = incl - v;                         // wbase[W] = all entries
+}
+static constexpr uint32_t kStageEntries = kSlice;                // a slice's entries staged in LDS: 128 KB
+__global__ void __launch_bounds__(1024)
+k_sort_coarse_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
+                      const uint32_t *__restrict__ wbase, uint32_t *__restrict__ centries) {
+    __shared__ uint32_t cnt[kMaxParts], start[kMaxParts + 1], stage[kStageEntries];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
+    if (t < kMaxParts) cnt[t] = 0;
+    __syncthreads();
+    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    for (uint32_t i = lo + t; i < hi; i += 1024u) {
+        const uint32_t v = digits[(size_t)w * pl.n + i];
+        if (v) atomicAdd(&cnt[((v >> 1) - 1u) >> kFineBits], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix of the <= 512 counters (threads 0 .. 511, Hillis-Steele in place through `start`)
+    if (t < kMaxParts) start[t + 1] = cnt[t];
+    if (t == 0) start[0] = 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < kMaxParts; off <<= 1) {
+        uint32_t v = 0;
+        if (t < kMaxParts && t + 1 > off) v = start[t + 1 - off];
+        __syncthreads();
+        if (t < kMaxParts) start[t + 1] += v;
+        __syncthreads();
+    }
+    if (t < kMaxParts) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + t; i < hi; i += 1024u) {
+        const uint32_t v = digits[(size_t)w * pl.n + i];
+        if (v) {
+            const uint32_t b = (v >> 1) - 1u, p = b >> kFineBits;
+            const uint32_t rank = atomicAdd(&cnt[p], 1u);
+            stage[start[p] + rank] = (i << 8) | ((v & 1u) << 7) | (b & (kFine - 1u));
+        }
+    }
+    __syncthreads();
+    const uint32_t total = start[parts], base = wbase[w];
+    const uint32_t *crow = chist + (size_t)w * kMaxParts * nslices;
+    for (uint32_t k = t; k < total; k += 1024u) {
+        uint32_t a = 0, b = parts;                               // partition of staged position k: start[a] <= k < start[a + 1]
+        while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if (start[mid] <= k) a = mid; else b = mid; }
+        centries[base + crow[(size_t)a * nslices + slice] + (k - start[a])] = stage[k];
+    }
+}
+static constexpr uint32_t kFineStage = 16384;                    // entries of a partition staged in LDS (4x the mean at 2^20)
+__global__ void __launch_bounds__(512)
+k_sort_fine(const uint32_t *__restrict__ centries, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
+            const uint32_t *__restrict__ wbase, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t fh[kFine], fstart[kFine + 1], stage[kFineStage];
+    const uint32_t part = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
+    if (part >= parts) return;
+    const uint32_t *crow = chist + (size_t)w * kMaxParts * nslices;
+    const uint32_t begin = wbase[w] + crow[(size_t)part * nslices];
+    const uint32_t end = part + 1u < parts ? wbase[w] + crow[(size_t)(part + 1u) * nslices] : wbase[w + 1];
+    const uint32_t count = end - begin;
+    if (t < kFine) fh[t] = 0;
+    __syncthreads();
+    for (uint32_t k = t; k < count; k += 512u) atomicAdd(&fh[centries[begin + k] & (kFine - 1u)], 1u);
+    __syncthreads();
+    if (t < kFine) { counts[(size_t)w * pl.B + (size_t)part * kFine + t] = fh[t]; fstart[t + 1] = fh[t]; }
+    if (t == 0) fstart[0] = 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < kFine; off <<= 1) {
+        uint32_t v = 0;
+        if (t < kFine && t + 1 > off) v = fstart[t + 1 - off];
+        __syncthreads();
+        if (t < kFine) fstart[t + 1] += v;
+        __syncthreads();
+    }
+    if (t < kFine) fh[t] = 0;
+    __syncthreads();
+    const bool staged = count <= kFineStage;                     // uniform
+    for (uint32_t k = t; k < count; k += 512u) {
+        const uint32_t c = centries[begin + k], f = c & (kFine - 1u);
+        const uint32_t pos = fstart[f] + atomicAdd(&fh[f], 1u), ent = ((c >> 8) << 1) | ((c >> 7) & 1u);
+        if (staged) stage[pos] = ent; else entries[begin + pos] = ent;
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t k = t; k < count; k += 512u) entries[begin + k] = stage[k];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
@@ -1272,15 +1417,24 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
     HIPCHK(e->digits.reserve((size_t)pl.W * n * 4));                               // digits [W][n]
-    HIPCHK(e->hist16.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
-    HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * nslices * nbmax * 4, rc_bytes)));   // base [W][slices][nbmax]; after the scatter: the row / column sums
+    // c = 16 plans below 2^24 records: the partitioned sort (k_sort_*); EIP2537_SORT2=0 or any other plan: direct scatter
+    static const bool env_sort2 = [] { const char *v = getenv("EIP2537_SORT2"); return !v || atoi(v) != 0; }();
+    const bool sort2 = env_sort2 && pl.c == 16 && n < (1u << 24) && (pl.B % kFine) == 0 && (pl.BT % kFine) == 0 &&
+                       (std::max(pl.B, pl.BT) >> kFineBits) <= kMaxParts && pl.W < 64;
+    if (sort2) {
+        HIPCHK(e->hist16.reserve((size_t)pl.W * kMaxParts * nslices * 4));            // partition counts [W][parts][slices]
+        HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * n * 4, rc_bytes)));      // entries in partition order; later the row / column sums
+    } else {
+        HIPCHK(e->hist16.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
+        HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * nslices * nbmax * 4, rc_bytes)));   // base [W][slices][nbmax]; after the scatter: the row / column sums
+    }
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges
+    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4 + 2 * 64 * 4));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges + window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
@@ -1336,26 +1490,36 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             HIPCHK(hipMemcpyAsync(static_cast<char *>(e->input.p) + (size_t)r0 * rec_bytes, static_cast<const char *>(e->host_src) + (size_t)r0 * rec_bytes,
                                   (size_t)(r1 - r0) * rec_bytes, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_msm_decode<F>, dim3((r1 - r0 + 255u) / 256u), dim3(256), 0, s, in, pl, pts, ptl, digits, err, r0, r1);
-            hipLaunchKernelGGL(k_msm_hist, dim3(sl1 - sl0, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, sl0);
+            if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(sl1 - sl0, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, sl0);
         }
     } else {
         if (e->host_src)
             HIPCHK(hipMemcpyAsync(e->input.p, e->host_src, n * (size_t)Wire<F>::kMsmRecWords * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, ptl, digits, err, 0u, (uint32_t)n);
-        hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
+        if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     }
     e->host_src = nullptr;
-    hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
     uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
+    if (sort2) {
+        uint32_t *wtotal = blk + 2048 + 264, *wbase = wtotal + 64;
+        hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16);
+        hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, pl, nslices, wtotal);
+        hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
+        hipLaunchKernelGGL(k_sort_coarse_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16, wbase, base);
+        hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, pl, nslices, hist16, wbase, entries, counts);
+    } else {
+        hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
+    }
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
+    if (!sort2)
+        hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2, lenhist, gshift, split_g);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;

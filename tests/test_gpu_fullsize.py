@@ -152,6 +152,12 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
         pool = [rng.scalar256() for _ in range(97)]
         few = b"".join(base[i * 160:i * 160 + 128] + m.encode_scalar(pool[(i * 31) % 97]) for i in range(m20))
         assert clib.call("bls12_g1multiexp", few) == (0, X.g1_multiexp(few))
+        # the partitioned sort of the c = 16 plans (k_sort_*): a ragged second slice (32 768 + 7 233 records), and G2
+        rag = X.gen_msm_input("g1", 40001, A, B, 4001)
+        assert clib.call("bls12_g1multiexp", rag) == (0, X.g1_multiexp(rag))
+        g2 = X.gen_msm_input("g2", 3001, A, B, 3001)
+        assert clib.call("bls12_g2multiexp", g2) == (0, X.g2_multiexp(g2))
+        assert X.last_plan()["window_bits"] == 16
     finally:
         X.set_window(0)
     # G2 with a heavy top window
