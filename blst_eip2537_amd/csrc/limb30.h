@@ -144,8 +144,25 @@ HD FpL fpl_take_high(const uint64_t *col) {
     }
     return r;
 }
-// a b / 2^390 + (< p), for a b < 630 p^2.  Column bound as fp_mul_cols30_t: columns 8 .. 16 are carried
-// out once, after outer step 7.
+// Column overflow.  Every limb is < 2^30, so a product term is <= (2^30 - 1)^2 and 16 of them fit a 64-bit column; a
+// column of the 13 x 13 product takes up to 13, and the reduction adds m p_j terms on top (with the real limbs of p: at most
+// 6.9 x 2^60 per column).  tools/limb_column_bounds.py tracks the exact worst case of every column through the schedules
+// below and finds the fewest carry-outs that keep all of them below 2^64: columns 10 .. 14 once for a product or a square
+// (round 2 carried 8 .. 16), and for the two-product sum 6 .. 18 after row 7 of both products plus column 12 before the
+// reduction (round 2: 8 .. 16 and 4 .. 20).  A carry-out moves only the HIGH DWORD (x 4 into the next column, 2^32 =
+// 4 x 2^30), which is one multiply-add and a clear instead of a 64-bit shift, a 64-bit add and a mask; the column keeps its
+// low 32 bits.
+HD void col_carry_hi(uint64_t *col, int c) {
+    const uint32_t hi = (uint32_t)(col[c] >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the compiler turns hi * 4 into a 64-bit shift, two masks and a 64-bit add)
+    asm("v_mad_u64_u32 %0, vcc, %1, 4, %2" : "=v"(col[c + 1]) : "v"(hi), "v"(col[c + 1]) : "vcc");
+#else
+    col[c + 1] += (uint64_t)hi << 2;
+#endif
+    col[c] &= 0xffffffffull;
+}
+// a b / 2^390 + (< p), for a b < 630 p^2.
 HD FpL mulL(const FpL &a, const FpL &b) {
     const uint32_t p30[13] = {K_P30};
     uint64_t col[27];
@@ -161,7 +178,7 @@ HD FpL mulL(const FpL &a, const FpL &b) {
         col[i + 1] += col[i] >> 30;
         if (i == 7) {
 #pragma unroll
-            for (int c = 8; c <= 16; c++) { col[c + 1] += col[c] >> 30; col[c] &= (uint64_t)kM30; }
+            for (int c = 10; c <= 14; c++) col_carry_hi(col, c);
         }
     }
     return fpl_take_high(col);
@@ -180,9 +197,9 @@ HD FpL sqrL(const FpL &a) {
 #pragma unroll
         for (int j = i + 1; j < 13; j++) col[i + j] += (uint64_t)a2[j] * a.l[i];
     }
-    // at most 7 terms of < 2^61 per column so far; carry 8 .. 16 out before the reduction adds 13 more
+    // at most 7 terms of < 2^61 per column so far; the reduction adds 13 more
 #pragma unroll
-    for (int c = 8; c <= 16; c++) { col[c + 1] += col[c] >> 30; col[c] &= (uint64_t)kM30; }
+    for (int c = 10; c <= 14; c++) col_carry_hi(col, c);
 #pragma unroll
     for (int i = 0; i < 13; i++) {
         const uint32_t m = ((uint32_t)col[i] * K_N0_30) & kM30;
@@ -194,9 +211,8 @@ HD FpL sqrL(const FpL &a) {
 }
 
 // (a b + c d) / 2^390 + (< p) with ONE reduction, for a b + c d < 630 p^2: 169 multiply-adds and a carry
-// pass less than two products and an addition.  Columns 8 .. 16 are carried out after the first 169
-// products (13 terms each), columns 4 .. 20 after the second (the reduction adds up to 13 more terms;
-// the columns outside hold at most 8 product terms).
+// pass less than two products and an addition.  The rows of the two products alternate; after row 7 of both a column
+// holds at most 16 terms.
 HD FpL mul2L(const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
     const uint32_t p30[13] = {K_P30};
     uint64_t col[27];
@@ -206,16 +222,14 @@ HD FpL mul2L(const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
     for (int i = 0; i < 13; i++) {
 #pragma unroll
         for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)a.l[j] * b.l[i];
-    }
-#pragma unroll
-    for (int k = 8; k <= 16; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)kM30; }
-#pragma unroll
-    for (int i = 0; i < 13; i++) {
 #pragma unroll
         for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)c.l[j] * d.l[i];
-    }
+        if (i == 7) {
 #pragma unroll
-    for (int k = 4; k <= 20; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)kM30; }
+            for (int k = 6; k <= 18; k++) col_carry_hi(col, k);
+        }
+    }
+    col_carry_hi(col, 12);
 #pragma unroll
     for (int i = 0; i < 13; i++) {
         const uint32_t m = ((uint32_t)col[i] * K_N0_30) & kM30;

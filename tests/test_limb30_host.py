@@ -54,3 +54,11 @@ def test_host_ifma_arithmetic_matches_scalar(tmp_path):
     for part in ("vector field operations", "cyclotomic squaring chains", "Fp12 products",
                  "exponentiation by z, final exponentiation, Horner"):
         assert part + ": 0 mismatches" in out.stdout, out.stdout
+
+
+def test_limb_form_column_accumulators_cannot_overflow():
+    """tools/limb_column_bounds.py: exact worst case of every 64-bit column of mulL / sqrL / mul2L under the carry-out
+    schedules of csrc/limb30.h (limbs < 2^30, the real limbs of p)."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "limb_column_bounds.py")], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout

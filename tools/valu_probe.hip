@@ -25,6 +25,13 @@ __global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed) {
             if (KIND == 3) u[i] = __umul24(u[i], b) + a;                                // v_mad_u32_u24
             if (KIND == 4) d[i] = __builtin_fma(d[i], 1.0000001, 0.5);                   // v_fma_f64
             if (KIND == 5) u[i] = u[i] + b + (u[i] >> 3);                                // plain 32-bit adds
+            // the carry handling around the multiply-adds of the limb form (round 3): is a 64-bit shift / add full rate?
+            if (KIND == 6) asm volatile("v_lshrrev_b64 %0, 3, %1" : "=v"(acc[i]) : "v"(acc[i]));
+            if (KIND == 7) asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(acc[i]) : "v"(acc[i]), "v"(acc[(i + 1) % CHAINS]));
+            if (KIND == 8) asm volatile("v_and_b32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(b));
+            if (KIND == 9) asm volatile("v_alignbit_b32 %0, %1, %2, 30" : "=v"(u[i]) : "v"(u[i]), "v"(b));
+            if (KIND == 10) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(acc[i]) : "v"(u[i]), "v"(acc[i]) : "vcc");
+            if (KIND == 11) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(b));
         }
     }
     uint32_t r = 0;
@@ -59,5 +66,11 @@ int main() {
     run<3>("v_mad_u32_u24", d_out, 1);
     run<4>("v_fma_f64", d_out, 1);
     run<5>("v_add_u32 x2 + shift", d_out, 3);
+    run<6>("v_lshrrev_b64", d_out, 1);
+    run<7>("v_lshl_add_u64", d_out, 1);
+    run<8>("v_and_b32", d_out, 1);
+    run<9>("v_alignbit_b32", d_out, 1);
+    run<10>("v_mad_u64_u32 (x, 1, acc)", d_out, 1);
+    run<11>("v_mul_lo_u32", d_out, 1);
     return 0;
 }
