@@ -160,9 +160,10 @@ HD Fp fp_mul_limbs32(const Fp &a, const Fp &b) {
 
 // ---- radix 2^30 (13 limbs) ------------------------------------------------------------------------------
 // 13 x 13 + 13 x 13 = 338 multiply-adds instead of the 392 of the 14 x 28-bit form below.  A column of
-// 26 products of 30-bit limbs would overflow its 64-bit accumulator by 0.7 bit, so the columns that can
-// collect more than 16 terms (8 .. 16) are carried out ONCE, after outer step 7, when each of them holds at
-// most 16 terms (16 (2^30 - 1)^2 + 2^34 < 2^64); the five remaining steps add at most 10 more.  The
+// 26 products of 30-bit limbs would overflow its 64-bit accumulator by 0.7 bit; with the real limbs of p the
+// reduction's share of a column is at most 6.9 x 2^60, and carrying columns 10 .. 14 out ONCE, after outer step 7,
+// keeps every column below 2^64 (exact worst case per column: tools/limb_column_bounds.py; round 2 carried
+// 8 .. 16 with a full shift / add / mask each).  The
 // reduction clears 12 x 30 + 24 = 384 bits, so R = 2^384 and the results are bit-identical to every other
 // product in this file.  Inputs may be in [0, 2p) (FpI); REDUCE = false leaves the result below 1.41 p.
 // hipcc (ROCm 7.2, gfx950) miscompiles the 13-limb product when it can see that the last reduction
@@ -177,6 +178,18 @@ HD Fp fp_mul_limbs32(const Fp &a, const Fp &b) {
 #else
 #define EIP_OPAQUE(x)
 #endif
+// Carry-out of a 64-bit column accumulator of the 30-bit-limb products: the HIGH DWORD moves into the next column (x 4:
+// 2^32 = 4 x 2^30), the column keeps its low 32 bits.  Which columns need it and when: limb30.h / tools/limb_column_bounds.py.
+HD void col_carry_hi(uint64_t *col, int c) {
+    const uint32_t hi = (uint32_t)(col[c] >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the compiler turns hi * 4 into a 64-bit shift, two masks and a 64-bit add)
+    asm("v_mad_u64_u32 %0, vcc, %1, 4, %2" : "=v"(col[c + 1]) : "v"(hi), "v"(col[c + 1]) : "vcc");
+#else
+    col[c + 1] += (uint64_t)hi << 2;
+#endif
+    col[c] &= 0xffffffffull;
+}
 template <bool REDUCE> HD Fp fp_mul_cols30_t(const Fp &a, const Fp &b) {
     const uint32_t p30[13] = {K_P30};
     const uint32_t M30 = 0x3fffffffu;
@@ -206,7 +219,7 @@ template <bool REDUCE> HD Fp fp_mul_cols30_t(const Fp &a, const Fp &b) {
         if (i < 12) col[i + 1] += col[i] >> 30;
         if (i == 7) {
 #pragma unroll
-            for (int c = 8; c <= 16; c++) { col[c + 1] += col[c] >> 30; col[c] &= (uint64_t)M30; }
+            for (int c = 10; c <= 14; c++) col_carry_hi(col, c);
         }
     }
     // digits 12..25 hold (result << 24); propagate carries, then cut 32-bit words at bit 24
@@ -230,8 +243,8 @@ template <bool REDUCE> HD Fp fp_mul_cols30_t(const Fp &a, const Fp &b) {
     return REDUCE ? fp_reduce_once(r) : r;
 }
 // Squaring: the 78 cross products are computed once against a doubled operand (91 + 169 multiply-adds);
-// the product phase leaves at most 13 terms per column, columns 8 .. 16 are carried out before the
-// reduction adds up to 13 more.
+// the product phase leaves at most 13 terms per column, columns 10 .. 14 are carried out before the
+// reduction adds its terms (limb30.h).
 template <bool REDUCE> HD Fp fp_sqr_cols30_t(const Fp &a) {
     const uint32_t p30[13] = {K_P30};
     const uint32_t M30 = 0x3fffffffu;
@@ -256,7 +269,7 @@ template <bool REDUCE> HD Fp fp_sqr_cols30_t(const Fp &a) {
         for (int j = i + 1; j < 13; j++) col[i + j] += (uint64_t)a2[j] * al[i];
     }
 #pragma unroll
-    for (int c = 8; c <= 16; c++) { col[c + 1] += col[c] >> 30; col[c] &= (uint64_t)M30; }
+    for (int c = 10; c <= 14; c++) col_carry_hi(col, c);
 #pragma unroll
     for (int i = 0; i < 13; i++) {
         uint32_t m = ((uint32_t)col[i] * K_N0_30) & (i < 12 ? M30 : 0x00ffffffu);
@@ -288,8 +301,8 @@ template <bool REDUCE> HD Fp fp_sqr_cols30_t(const Fp &a) {
 // (a b + c d) / 2^384 with ONE reduction: the component of an Fp2 product (u0 v0 - u1 v1, u0 v1 + u1 v0)
 // in 507 multiply-adds instead of two products and an addition (676 + a carry chain).  Inputs in [0, 2p):
 // the sum is below 8 p^2, so the result is below 8 p^2 / R + p = 1.82 p -- inside the lazy range of FpI.
-// Columns 8 .. 16 are carried out after the first 169 products, columns 4 .. 20 after the second; the
-// reduction is the one of fp_mul_cols30_t (its last factor hidden from the optimiser, see above).
+// The rows of the two products alternate, columns 6 .. 18 are carried out after row 7 of both and column 12 before the
+// reduction (limb30.h); the reduction is the one of fp_mul_cols30_t (its last factor hidden from the optimiser, see above).
 HD Fp fp_mul2_cols30(const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
     const uint32_t p30[13] = {K_P30};
     const uint32_t M30 = 0x3fffffffu;
@@ -312,16 +325,14 @@ HD Fp fp_mul2_cols30(const Fp &a, const Fp &b, const Fp &c, const Fp &d) {
     for (int i = 0; i < 13; i++) {
 #pragma unroll
         for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)al[j] * bl[i];
-    }
-#pragma unroll
-    for (int k = 8; k <= 16; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)M30; }
-#pragma unroll
-    for (int i = 0; i < 13; i++) {
 #pragma unroll
         for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)cl[j] * dl[i];
-    }
+        if (i == 7) {
 #pragma unroll
-    for (int k = 4; k <= 20; k++) { col[k + 1] += col[k] >> 30; col[k] &= (uint64_t)M30; }
+            for (int k = 6; k <= 18; k++) col_carry_hi(col, k);
+        }
+    }
+    col_carry_hi(col, 12);
 #pragma unroll
     for (int i = 0; i < 13; i++) {
         uint32_t m = ((uint32_t)col[i] * K_N0_30) & (i < 12 ? M30 : 0x00ffffffu);

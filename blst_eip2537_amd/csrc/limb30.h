@@ -151,17 +151,7 @@ HD FpL fpl_take_high(const uint64_t *col) {
 // (round 2 carried 8 .. 16), and for the two-product sum 6 .. 18 after row 7 of both products plus column 12 before the
 // reduction (round 2: 8 .. 16 and 4 .. 20).  A carry-out moves only the HIGH DWORD (x 4 into the next column, 2^32 =
 // 4 x 2^30), which is one multiply-add and a clear instead of a 64-bit shift, a 64-bit add and a mask; the column keeps its
-// low 32 bits.
-HD void col_carry_hi(uint64_t *col, int c) {
-    const uint32_t hi = (uint32_t)(col[c] >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // (the compiler turns hi * 4 into a 64-bit shift, two masks and a 64-bit add)
-    asm("v_mad_u64_u32 %0, vcc, %1, 4, %2" : "=v"(col[c + 1]) : "v"(hi), "v"(col[c + 1]) : "vcc");
-#else
-    col[c + 1] += (uint64_t)hi << 2;
-#endif
-    col[c] &= 0xffffffffull;
-}
+// low 32 bits (col_carry_hi, field.h -- the 12 x 32-bit products there follow the same schedules).
 // a b / 2^390 + (< p), for a b < 630 p^2.
 HD FpL mulL(const FpL &a, const FpL &b) {
     const uint32_t p30[13] = {K_P30};

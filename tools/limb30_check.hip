@@ -57,7 +57,9 @@ int main() {
         Fp v = from_limbs(x);
         for (int r = 0; r < 12; r++) v = fp_reduce_once(v);
         const Fp got = mul(mul(fp_reduce_once(to_fpi(sqrL(x)).v), r390), r390);
-        const bool ok = eq(got, mul(v, v));
+        // the same operand through the general product and the two-product sum (their own carry-out schedules)
+        const Fp sq = canon_of(sqrL(x));
+        const bool ok = eq(got, mul(v, v)) && eq(canon_of(mulL(x, x)), sq) && eq(canon_of(mul2L(x, x, x, x)), add(sq, sq));
         printf("extreme limbs: %s\n", ok ? "ok" : "MISMATCH");
         if (!ok) bad++;
     }
