@@ -1210,19 +1210,29 @@ k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__
     // row job: buckets 256 job + (sub + i lj);   column job: buckets 256 (sub + i lj) + job
     const uint32_t first = w * B + (is_row ? job * kRcCols + sub : sub * kRcCols + job);
     const uint32_t step = is_row ? lj : lj * kRcCols;
-    auto fetch = [&](uint32_t i, Xyzz<FpL> &pt) {
-        const uint32_t g = first + i * step;
-        const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+    // bucket i's slot range is looked up two additions ahead and its point one addition ahead: with one wave per SIMD
+    // nothing else hides the two dependent loads (slot range, then the 224-byte point)
+    auto slots = [&](uint32_t i, uint32_t &t0, uint32_t &t1) {
+        const uint32_t g = first + min(i, kRcChain - 1u) * step;
+        t0 = taskoff[g];
+        t1 = taskoff[g + 1];
+    };
+    auto fetch = [&](uint32_t t0, uint32_t t1, Xyzz<FpL> &pt) {
         if (t1 > t0) pt = partial[t0];                                  // multi-task buckets were folded into slot t0
         else pt = xyzz_inf<FpL>();
     };
     Xyzz<FpL> acc, nxt;
-    fetch(0, acc);
-    fetch(1, nxt);
+    uint32_t a0, a1, b0, b1;
+    slots(0, a0, a1);
+    slots(1, b0, b1);
+    fetch(a0, a1, acc);
+    fetch(b0, b1, nxt);
+    slots(2, a0, a1);
 #pragma unroll 1
     for (uint32_t i = 1; i < kRcChain; i++) {
         const Xyzz<FpL> cur = nxt;
-        if (i + 1 < kRcChain) fetch(i + 1, nxt);                        // in flight during the addition below
+        if (i + 1 < kRcChain) fetch(a0, a1, nxt);                       // in flight during the addition below
+        slots(i + 2, a0, a1);
         acc = add(acc, cur);
     }
     const int lane = threadIdx.x & 63;

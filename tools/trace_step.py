@@ -1,6 +1,7 @@
 """Print the kernel timeline of one call from a rocprofv3 kernel trace: tools/trace_step.py <dir> <first-kernel-substring> [index]"""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if sys.argv[2] in r["Kernel_Name"]]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else len(starts) // 2
