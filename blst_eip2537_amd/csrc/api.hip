@@ -346,7 +346,10 @@ template <> int msm_dispatch<Fp2>(Engine *e, const void *d_in, size_t n, uint32_
 // One device pipeline on pool `pi` (-1: least busy listed device).  device_input: `in` is already in
 // HBM on that pool's device; want_partial: write the projective partial instead of the encoding.
 template <class F>
-static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_input, bool want_partial) {
+static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_input, bool want_partial, CopyGate *gate = nullptr, int turn = 0) {
+    // a shard of a pipelined call takes its engine slot only when it is its turn to copy: a slot holder never waits for another
+    // shard, so concurrent pipelined calls cannot starve each other of slots
+    if (gate) gate->wait_turn(turn);
     SlotLease lease(pi);
     Engine *e = lease.e;
     if (!e) return E_MEMORY_ERROR;
@@ -359,11 +362,14 @@ static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_in
             return E_MEMORY_ERROR;
         }
         e->host_src = in;
+        e->copy_gate = gate;
+        e->copy_turn = turn;
         d_in = e->input.p;
     }
     Xyzz<F> acc;
     int st = msm_dispatch<F>(e, d_in, n, reinterpret_cast<uint32_t *>(&acc));
     e->host_src = nullptr;                      // never retained past the call (an early error return leaves it set)
+    e->copy_gate = nullptr;
     if (st) return st;
     if (want_partial) {
         memcpy(out, &acc, sizeof acc);
@@ -627,6 +633,28 @@ template <class Fn> static void run_shards(size_t shards, Fn &&fn) {
     g_last = t_last;
 }
 
+// Shards of a pipelined single-device call (msm_host_abi), from profiles/r03_h2d_pipeline.txt: G1 from 2^19 records in shards of
+// about 350 000 (2^20: 2 / 3 / 4 shards 5.64 / 5.49 / 5.58 ms against 6.74 for one pipeline; below 2^19 a shard's pipeline is
+// mostly fixed latency and nothing is gained), G2 -- three times the arithmetic for 1.8 times the bytes per record -- from 2^18
+// in shards of 2^17 (2^18: 6.00 -> 5.52 ms; 2^17: no gain); at most 6 of the device's engine slots.
+// EIP2537_H2D_PIPELINE=0: one copy, one pipeline; k >= 2: k shards whatever the size (A/B).
+template <class F> static size_t pipeline_shards(size_t n) {
+    static const int mode = [] { const char *v = getenv("EIP2537_H2D_PIPELINE"); return v ? atoi(v) : 1; }();
+    const size_t cap = std::min<size_t>(6, (size_t)g_nslots);
+    if (mode >= 2) return n >= (size_t)1024 * (size_t)mode ? (size_t)mode : 1;
+    if (mode == 0 || g_window_override.load() != 0) return 1;
+    const bool g1 = sizeof(F) == sizeof(Fp);
+    if (n < (g1 ? (size_t)1 << 19 : (size_t)1 << 18)) return 1;
+    return std::min(cap, std::max<size_t>(2, g1 ? n / 349525 : n >> 17));
+}
+static int least_busy_pool() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!device_select_locked()) return -1;
+    int pi = g_split[0];
+    for (int i = 1; i < g_nsplit; i++)
+        if (g_pools[g_split[i]].nbusy < g_pools[pi].nbusy) pi = g_split[i];
+    return pi;
+}
 template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_len) {
     const size_t rec = Wire<F>::kMsmRecWords * 4;
     if (in_len == 0 || in_len % rec) return E_INVALID_LENGTH;      // before touching `in`
@@ -634,14 +662,27 @@ template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_
     if (host_route(n, HostMax<F>::kUnits)) return device_present() ? msm_host_small<F>(out, in, n) : E_MEMORY_ERROR;
     if (n >= CoalesceCfg<F>::kMinRecords && n <= CoalesceCfg<F>::kMaxRecords && coalesce_enabled() && g_window_override.load() == 0)
         return msm_coalesced<F>(out, in, n);
-    const std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
-    if (pools.empty()) return msm_entry<F>(-1, out, in, n, false, false);
+    std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
+    CopyGate gate;
+    bool pipelined = false;
+    if (pools.empty()) {
+        // One device, a large G1 input: the 168 MB copy of 2^20 records (3.2 ms at the link's ~53 GB/s) is as long as the whole
+        // device pipeline, and a sum over records can be cut anywhere -- so the input is cut into 2 .. 4 contiguous shards on
+        // engine slots of the SAME device whose copies follow each other (CopyGate) while the earlier shards compute.
+        const size_t k = pipeline_shards<F>(n);
+        if (k < 2) return msm_entry<F>(-1, out, in, n, false, false);
+        const int pi = least_busy_pool();
+        if (pi < 0) return E_MEMORY_ERROR;
+        pools.assign(k, pi);
+        pipelined = true;
+    }
     const size_t shards = pools.size();
     std::vector<Xyzz<F>> parts(shards);
     std::vector<int> rc(shards, E_MEMORY_ERROR);
     run_shards(shards, [&](size_t s) {
         const size_t lo = n * s / shards, hi = n * (s + 1) / shards;
-        rc[s] = msm_entry<F>(pools[s], reinterpret_cast<byte *>(&parts[s]), in + lo * rec, hi - lo, false, true);
+        rc[s] = msm_entry<F>(pools[s], reinterpret_cast<byte *>(&parts[s]), in + lo * rec, hi - lo, false, true, pipelined ? &gate : nullptr, (int)s);
+        if (pipelined) gate.done((int)s);          // whatever happened: the next shard may copy
     });
     for (size_t s = 0; s < shards; s++)
         if (rc[s]) return rc[s];

@@ -3,6 +3,8 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <mutex>
 
 namespace eip {
 
@@ -26,6 +28,26 @@ struct LastPlan {
     uint32_t buckets;  // MSM buckets (0 for a pairing batch)
 };
 
+// Order of the host -> device copies of the shards of ONE host-input call that share a device (api.hip, msm_host_abi):
+// shard s stages its records only after shard s - 1 has handed its own to the copy engine, so that the shards' pipelines
+// run one behind the other -- shard s computes while shard s + 1 copies -- instead of sharing the PCIe link.
+struct CopyGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int turn = 0;
+    void wait_turn(int s) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return turn >= s; });
+    }
+    void done(int s) {                             // idempotent; also called when a shard fails before its copy
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (turn < s + 1) turn = s + 1;
+        }
+        cv.notify_all();
+    }
+};
+
 struct Engine {
     bool ready = false;
     bool failed = false;   // a HIP call failed mid-pipeline: the slot is drained and rebuilt on release
@@ -34,6 +56,8 @@ struct Engine {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr, ev_c = nullptr;
     // staging + per-call workspace (grow-only)
     DevBuf input;          // H2D copy of a host caller's records
+    CopyGate *copy_gate = nullptr;    // set with host_src by a shard of a pipelined host-input call
+    int copy_turn = 0;
     const void *host_src = nullptr;   // set by a host-input MSM call: the pipeline stages `input` from here itself, in chunks (msm.hip)
     DevBuf misc;           // first-error word, scan totals, split-bucket counters
     // MSM

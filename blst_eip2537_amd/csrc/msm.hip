@@ -1503,8 +1503,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(sl1 - sl0, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, sl0);
         }
     } else {
-        if (e->host_src)
-            HIPCHK(hipMemcpyAsync(e->input.p, e->host_src, n * (size_t)Wire<F>::kMsmRecWords * 4, hipMemcpyHostToDevice, s));
+        if (e->host_src) {
+            const hipError_t ce = hipMemcpyAsync(e->input.p, e->host_src, n * (size_t)Wire<F>::kMsmRecWords * 4, hipMemcpyHostToDevice, s);
+            if (e->copy_gate) e->copy_gate->done(e->copy_turn);            // shards of one call on one device copy in shard order (api.hip); a pageable copy returns when its last chunk is staged
+            HIPCHK(ce);
+        }
         hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, ptl, digits, err, 0u, (uint32_t)n);
         if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     }

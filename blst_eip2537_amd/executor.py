@@ -63,6 +63,30 @@ def lib_path():
     return _SO
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (torch/lib); the engine
+    library asks for the same soname and would otherwise map /opt/rocm's copy when it is loaded first -- and whichever of the
+    two runtimes opens the device second then reports "no ROCm-capable device".  So when PyTorch is installed but not imported
+    yet, its copy is mapped first (without importing torch) and the loader binds the engine to it, exactly as it does when
+    `import torch` came first.  Without PyTorch the engine uses the ROCm installation's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the in-tree engine library; fail loudly if it has not been built."""
     global _lib
@@ -72,6 +96,7 @@ def lib():
         raise RuntimeError(
             "libeip2537_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C blst_eip2537_amd/csrc`.  There is no CPU fallback." % _SO)
+    _one_hip_runtime()
     L = ctypes.CDLL(_SO)
     for name in _ABI:
         f = getattr(L, name)

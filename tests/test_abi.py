@@ -118,3 +118,17 @@ def test_no_cpu_fallback_without_device(X):
     inp = m.encode_g1(m.G1) + m.encode_scalar(5)
     assert call_x(X.g1_multiexp, inp * 3) == (7, None)
     assert call_x(X.pairing, m.encode_g1(m.G1) + m.encode_g2(m.G2)) == (7, None)
+
+
+def test_python_layer_keeps_one_hip_runtime_in_the_process():
+    """PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both open the device (whichever
+    comes second reports "no ROCm-capable device").  The Python layer maps PyTorch's copy before the engine library when torch
+    is installed but not imported yet, so the order of `import torch` and the first engine call does not matter."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import blst_eip2537_amd as p\np.lib()\nimport torch\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "print('HIPLIBS', len(libs), libs)\n" % ROOT)
+    cp = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert "HIPLIBS 1 " in cp.stdout, cp.stdout[-2000:]

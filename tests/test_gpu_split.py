@@ -62,6 +62,35 @@ if mode == "small":                      # EIP2537_HIP_SPLIT_MIN=64: every call 
     e[20 * 384 + 128:20 * 384 + 384] = m.encode_g2((((1, 0)), ((1, 0))))         # off-curve G2, shard 0 -> wins
     assert call(X.pairing, bytes(e)) == (1, None)
     assert X.last_plan() is not None
+elif mode == "pipe":                     # ONE device, EIP2537_H2D_PIPELINE=3: every host-input call of >= 2^16 records runs as 3 shards
+    n = (1 << 16) + 1                    # whose copies follow each other on the same device (api.hip, pipeline_shards / CopyGate)
+    g1 = clib.gen_msm_input("g1", n, A, B, 4242)
+    assert call(X.g1_multiexp, g1) == clib.call("bls12_g1multiexp", g1)
+    assert X.last_plan()["units"] in (n // 3, n // 3 + 1), X.last_plan()
+    bad = bytearray(g1); bad[60000 * 160 + 0] = 1                      # pad byte: INVALID_ELEMENT in shard 2
+    assert call(X.g1_multiexp, bytes(bad)) == (3, None)
+    bad[10 * 160 + 16:10 * 160 + 128] = m.encode_g1((1, 1))[16:]       # (1,1) off curve in shard 0 -> wins
+    assert call(X.g1_multiexp, bytes(bad)) == (1, None)
+    gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
+    g2 = X.gen_msm_input("g2", 1 << 16, A, B, 0x25370100 + 16)
+    assert call(X.g2_multiexp, g2) == (0, gold("g2msm_2p16.hex"))
+    # concurrent pipelined calls: shards take their engine slot only when it is their turn to copy, so 6 callers x 3 shards
+    # on 8 slots cannot starve each other
+    import threading
+    want = clib.call("bls12_g1multiexp", g1)
+    res = [None] * 6
+    def worker(i): res[i] = call(X.g1_multiexp, g1)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert all(r == want for r in res)
+elif mode == "pipe_default":             # ONE device, default policy: 2^20 G1 records = 3 shards, 2^16 = one pipeline
+    gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
+    g1 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
+    assert call(X.g1_multiexp, g1) == (0, gold("g1msm_2p20.hex"))
+    assert X.last_plan()["units"] in (349525, 349526), X.last_plan()
+    g1s = X.gen_msm_input("g1", 1 << 16, A, B, 0x25370000 + 16)
+    assert call(X.g1_multiexp, g1s) == (0, gold("g1msm_2p16.hex"))
+    assert X.last_plan()["units"] == 1 << 16
 else:                                    # default thresholds at the BASELINE sizes
     gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
     g1 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
@@ -99,6 +128,14 @@ def test_split_three_pools_ragged(tmp_path, clib, X):
 
 def test_split_baseline_sizes_default_thresholds(tmp_path, clib, X):
     _run(tmp_path, "full", "0,0", {})
+
+
+def test_pipelined_host_input_three_shards_one_device(tmp_path, clib, X):
+    _run(tmp_path, "pipe", "0", {"EIP2537_H2D_PIPELINE": "3"})
+
+
+def test_pipelined_host_input_default_policy(tmp_path, clib, X):
+    _run(tmp_path, "pipe_default", "0", {})
 
 
 def test_device_ordinal_out_of_range_is_an_error(tmp_path):

@@ -1,6 +1,6 @@
 """ThreadSanitizer pass over the library's host concurrency code (the reference runs `go test -race`; this is
 the engine's own counterpart).  csrc/api.hip -- engine slot pool (SlotLease), coalescing queue (Batcher / coalesce),
-record-range split over devices (run_shards), last-call statistics -- is compiled for the host only against stand-ins for
+record-range split over devices (run_shards) and the pipelined shards of one device (CopyGate), last-call statistics -- is compiled for the host only against stand-ins for
 the HIP runtime and the device pipelines (tools/tsan/) and hammered from 24 threads: every result must equal the one the
 same call returns on an idle library and ThreadSanitizer must stay silent.  No GPU code is involved; the sanitizer build is
 never run on a GPU box (not a `gpu` test)."""
@@ -29,3 +29,10 @@ def test_host_concurrency_under_thread_sanitizer(tmp_path):
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert " 0 mismatches" in r.stdout and "coalesced" in r.stdout, r.stdout
+    # ONE stub device: the large G1 / G2 cases run as three shards on engine slots of the same device whose copies follow each
+    # other (api.hip: pipeline_shards, CopyGate) -- with only two slots, so that shards wait for slots while others hold them
+    env.update(EIP_STUB_NDEV="1", EIP2537_H2D_PIPELINE="3")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert " 0 mismatches" in r.stdout, r.stdout

@@ -8,14 +8,15 @@ X.init(0)
 A = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6
 B = 0x0123456789abcdef0fedcba987654321
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+grp = sys.argv[2] if len(sys.argv) > 2 else "g1"
 n = 1 << log2n
-inp = X.gen_msm_input("g1", n, A, B, 0x25370000 + log2n)
-gp = os.path.join(ROOT, "tests", "golden", "g1msm_2p%d.hex" % log2n)
+inp = X.gen_msm_input(grp, n, A, B, (0x25370000 if grp == "g1" else 0x25370100) + log2n)
+gp = os.path.join(ROOT, "tests", "golden", "%smsm_2p%d.hex" % (grp, log2n))
 gold = bytes.fromhex(open(gp).read().strip()) if os.path.exists(gp) else None
 ts = []
 for i in range(10):
     t0 = time.perf_counter()
-    out = X.g1_multiexp(inp)
+    out = X.g1_multiexp(inp) if grp == "g1" else X.g2_multiexp(inp)
     ts.append((time.perf_counter() - t0) * 1e3)
-print("H2D_CHUNKS=%s n=2^%d golden_ok=%s host-ABI ms min %.3f med %.3f" % (os.environ.get("EIP2537_H2D_CHUNKS", "default"), log2n,
+print(grp, "H2D_PIPELINE=%s H2D_CHUNKS=%s n=2^%d golden_ok=%s host-ABI ms min %.3f med %.3f" % (os.environ.get("EIP2537_H2D_PIPELINE", "default"), os.environ.get("EIP2537_H2D_CHUNKS", "default"), log2n,
       None if gold is None else out == gold, min(ts[2:]), sorted(ts[2:])[len(ts[2:]) // 2]), flush=True)

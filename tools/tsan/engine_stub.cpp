@@ -17,6 +17,7 @@ MsmPlan msm_make_plan(uint32_t n, int, bool) { MsmPlan p{}; p.n = n; p.c = 8; p.
 template <class F> static int msm_stub(Engine *e, const void *d_in, size_t n, Xyzz<F> *acc_out, Xyzz<F> *wins) {
     if (e->host_src) {                                        // host input: the real pipeline stages it itself (msm.hip)
         memcpy(e->input.p, e->host_src, n * Wire<F>::kMsmRecWords * 4);
+        if (e->copy_gate) e->copy_gate->done(e->copy_turn);  // a shard of a pipelined call: the next shard may copy (msm.hip)
         e->host_src = nullptr;
     }
     const uint32_t *in = static_cast<const uint32_t *>(d_in);
