@@ -1130,6 +1130,24 @@ k_msm_reduce8c(const Xyzz<Fp2> *__restrict__ partial, const uint32_t *__restrict
     }
 }
 
+// The blocks of a window leave one sum each (<= 12 per window at 2^16 records, 232 in all); adding them on the host cost 0.26 ms
+// of a 1.96 ms call (a host G2 addition is ~1.1 us), so one more wave per window does it here: group j of 8 lanes takes the
+// blocks j, j + 8, ..., then the tree over the 8 groups -- 4 to 5 additions deep.  winsum[w] = the window's whole sum.
+__global__ void __launch_bounds__(64, 1)
+k_msm_window_sum8c(const Xyzz<Fp2> *__restrict__ winout, MsmPlan pl, ReduceGrid rg, Xyzz<Fp2> *__restrict__ winsum) {
+    const int w = blockIdx.x, lane = threadIdx.x & 63, sl = lane & 7, gb = lane & ~7, q = sl & 1;
+    claim_whole_simd();
+    const PairProd8 prod(lane, sl, gb);
+    const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
+    Xyzz<FpI> C = xyzz_inf<FpI>();
+    for (uint32_t b = (uint32_t)(lane >> 3); b < nb; b += 8u) C = add8c(C, component_of(winout[b0 + b], q), prod);      // uniform in the group
+    for (int off = 8; off < 64; off <<= 1) {
+        Xyzz<FpI> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 8) C = add8c(C, o, prod);
+    }
+    if (lane < 2) store_component(&winsum[w], C, q);
+}
+
 // ---- bucket reduce, one lane per running sum (used for G1) ------------------------------------
 // Measured at 2^20 / c = 16: 1.55 ms against 1.8-2.1 ms for the 4-lane form above (whose per-round
 // select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
@@ -1318,7 +1336,10 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool li
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
+    hipLaunchKernelGGL(k_msm_window_sum8c, dim3(pl.W), dim3(64), 0, s, (const Xyzz<Fp2> *)winout, pl, rg, winout + red_blocks);     // -> W window sums behind the block sums
 }
+static constexpr bool window_sums_on_device(const Fp2 *) { return true; }
+static constexpr bool window_sums_on_device(const Fp *) { return false; }
 // Two-level reduce of a G1 c = 16 plan (k_msm_rowcol / k_msm_reduce_rc): the top window's upper half TB is accumulated, folded and
 // summed on stream3 beside the accumulate of everything else (TB's tasks finish long before the rest: 1 / 17 of the work); the
 // row / column launch on the critical path then is the 16 other virtual windows = exactly 1 024 waves.
@@ -1418,7 +1439,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return !v || atoi(v) != 0; }();
     const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B == kRcRows * kRcCols && pl.BT == 2u * pl.B;
     if (two_level) red_blocks = 2u * (uint32_t)(pl.W + 1);
-    const size_t nwin_out = red_blocks;
+    const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level;      // G2: one sum per window comes back, not one per block
+    const size_t nwin_out = dev_winsum ? (size_t)pl.W : red_blocks;
     const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
     const uint32_t split_g = two_level ? (uint32_t)pl.W * pl.B : 0xffffffffu;      // first bucket of the top window's upper half
     HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
@@ -1442,7 +1464,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
-    HIPCHK(e->winout.reserve(nwin_out * sizeof(Xyzz<F>)));
+    HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4 + 2 * 64 * 4));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges + window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
@@ -1558,7 +1580,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     std::vector<Xyzz<F>> hw(nwin_out);
     StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hw.data(), winout, nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hw.data(), winout + (dev_winsum ? red_blocks : 0u), nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     drain.armed = false;
     float ms = 0.f;
@@ -1579,6 +1601,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
                 for (int d = 0; d < pl.c / 2; d++) acc = dbl(acc);
                 acc = add(acc, hw[2 * w + h]);
             }
+    } else if (dev_winsum) {
+        for (int w = pl.W - 1; w >= 0; w--) {
+            for (int d = 0; d < pl.c; d++) acc = dbl(acc);
+            acc = add(acc, hw[(size_t)w]);
+        }
     } else
     for (int w = pl.W - 1; w >= 0; w--) {
         for (int d = 0; d < pl.c; d++) acc = dbl(acc);
