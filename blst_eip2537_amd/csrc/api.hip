@@ -13,6 +13,7 @@
 // without a working HIP device they fail loudly with EIP2537_MEMORY_ERROR.
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -662,27 +663,33 @@ template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_
     if (host_route(n, HostMax<F>::kUnits)) return device_present() ? msm_host_small<F>(out, in, n) : E_MEMORY_ERROR;
     if (n >= CoalesceCfg<F>::kMinRecords && n <= CoalesceCfg<F>::kMaxRecords && coalesce_enabled() && g_window_override.load() == 0)
         return msm_coalesced<F>(out, in, n);
+    // Record ranges: one per listed device when the input is at least two shards' worth (split_plan), and inside a device's range
+    // the pipelined shards of pipeline_shards(): the 168 MB copy of 2^20 G1 records (3.2 ms at the link's ~53 GB/s) is as long as
+    // the whole device pipeline and a sum over records can be cut anywhere, so a range is cut into 2 .. 6 contiguous shards on
+    // engine slots of the SAME device whose copies follow each other (CopyGate, one per device) while the earlier shards compute.
     std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
-    CopyGate gate;
-    bool pipelined = false;
     if (pools.empty()) {
-        // One device, a large G1 input: the 168 MB copy of 2^20 records (3.2 ms at the link's ~53 GB/s) is as long as the whole
-        // device pipeline, and a sum over records can be cut anywhere -- so the input is cut into 2 .. 4 contiguous shards on
-        // engine slots of the SAME device whose copies follow each other (CopyGate) while the earlier shards compute.
-        const size_t k = pipeline_shards<F>(n);
-        if (k < 2) return msm_entry<F>(-1, out, in, n, false, false);
+        if (pipeline_shards<F>(n) < 2) return msm_entry<F>(-1, out, in, n, false, false);
         const int pi = least_busy_pool();
         if (pi < 0) return E_MEMORY_ERROR;
-        pools.assign(k, pi);
-        pipelined = true;
+        pools.assign(1, pi);
     }
-    const size_t shards = pools.size();
+    struct Shard { int pool; size_t lo, hi; CopyGate *gate; int turn; };
+    std::vector<Shard> plan;
+    std::vector<std::unique_ptr<CopyGate>> gates;
+    for (size_t d = 0; d < pools.size(); d++) {
+        const size_t lo = n * d / pools.size(), hi = n * (d + 1) / pools.size(), k = pipeline_shards<F>(hi - lo);
+        gates.emplace_back(k > 1 ? new CopyGate : nullptr);
+        for (size_t t = 0; t < k; t++)
+            plan.push_back(Shard{pools[d], lo + (hi - lo) * t / k, lo + (hi - lo) * (t + 1) / k, gates.back().get(), (int)t});
+    }
+    const size_t shards = plan.size();
     std::vector<Xyzz<F>> parts(shards);
     std::vector<int> rc(shards, E_MEMORY_ERROR);
     run_shards(shards, [&](size_t s) {
-        const size_t lo = n * s / shards, hi = n * (s + 1) / shards;
-        rc[s] = msm_entry<F>(pools[s], reinterpret_cast<byte *>(&parts[s]), in + lo * rec, hi - lo, false, true, pipelined ? &gate : nullptr, (int)s);
-        if (pipelined) gate.done((int)s);          // whatever happened: the next shard may copy
+        const Shard &sh = plan[s];
+        rc[s] = msm_entry<F>(sh.pool, reinterpret_cast<byte *>(&parts[s]), in + sh.lo * rec, sh.hi - sh.lo, false, true, sh.gate, sh.turn);
+        if (sh.gate) sh.gate->done(sh.turn);       // whatever happened: the device's next shard may copy
     });
     for (size_t s = 0; s < shards; s++)
         if (rc[s]) return rc[s];
@@ -1158,6 +1165,27 @@ __global__ void k_limb_selftest(uint64_t seed, unsigned n, unsigned long long *b
         if (!eq(canon_of(mulL(big, D)), mul32(c, d))) atomicAdd(&bad[2], 1ull);
     }
     if (!eq(fp_reduce_once(fp_mul2_cols30(a, b, c, d)), add(mul32(a, b), mul32(c, d)))) atomicAdd(&bad[3], 1ull);
+    if (i < 64) {
+        // all-ones limbs (x = 2^384 - 1 < 10 p): the operand that fills the 64-bit columns the most -- the carry-out schedules of
+        // limb30.h / field.h are sized for it (tools/limb_column_bounds.py), and the device carries differ from the host's
+        // (col_carry_hi is an explicit v_mad_u64_u32 here).  x^2 / R through the limb square, the general product and the
+        // two-product sum against the 32-bit CIOS product of x mod p.
+        FpL x;
+#pragma unroll
+        for (int k = 0; k < 12; k++) x.l[k] = kM30;
+        x.l[12] = 0x00ffffffu;
+        Fp v = from_limbs(x);
+        for (int r = 0; r < 12; r++) v = fp_reduce_once(v);
+        const Fp want = mul32(v, v), sq = canon_of(sqrL(x));
+        if (!eq(mul32(mul32(sq, r390), r390), want)) atomicAdd(&bad[1], 1ull);
+        if (!eq(canon_of(mulL(x, x)), sq)) atomicAdd(&bad[0], 1ull);
+        if (!eq(canon_of(mul2L(x, x, x, x)), add(sq, sq))) atomicAdd(&bad[2], 1ull);
+        Fp w;
+#pragma unroll
+        for (int k = 0; k < 12; k++) w.l[k] = k == 11 ? 0x0fffffffu : 0xffffffffu;      // < 2^380: inside fp_mul2_cols30's [0, 2p) range
+        const Fp wr = fp_reduce_once(w);
+        if (!eq(fp_reduce_once(fp_mul2_cols30(w, w, w, w)), dbl(mul32(wr, wr)))) atomicAdd(&bad[3], 1ull);
+    }
     if (!eq(canon_of(A), a) || !eq(from_limbs(to_limbs(a)), a)) atomicAdd(&bad[4], 1ull);
     {
         const FpL big = selftest_grow(A, 100u + (i % 490u));
