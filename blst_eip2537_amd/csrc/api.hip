@@ -623,9 +623,19 @@ static std::vector<int> split_plan(size_t n, size_t min_per_shard) {
 template <class Fn> static void run_shards(size_t shards, Fn &&fn) {
     std::vector<std::thread> th;
     std::vector<CallStats> stats(shards);
-    for (size_t s = 1; s < shards; s++) th.emplace_back([&, s] { fn(s); stats[s] = t_last; });
+    th.reserve(shards);
+    size_t started = 1;
+    for (; started < shards; started++) {
+        const size_t s = started;
+        try {
+            th.emplace_back([&, s] { fn(s); stats[s] = t_last; });
+        } catch (...) {                            // no more threads: the remaining shards run on this thread, in order
+            break;
+        }
+    }
     fn(0);
     stats[0] = t_last;
+    for (size_t s = started; s < shards; s++) { fn(s); stats[s] = t_last; }
     for (auto &t : th) t.join();
     // the call's timing is that of its slowest shard
     for (size_t s = 1; s < shards; s++)
