@@ -116,8 +116,9 @@ template <class F> HD Xyzz<F> scalar_mul(const Aff<F> &a, const uint32_t *k, int
 }
 // [m]P for a small unsigned m and projective P (bucket-reduce offsets)
 template <class F> HD Xyzz<F> small_mul(const Xyzz<F> &p, uint32_t m) {
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (int i = 31 - __builtin_clz(m | 1u); i >= 0; i--) {
+    if (m == 0) return xyzz_inf<F>();
+    Xyzz<F> acc = p;                                 // the top bit
+    for (int i = 30 - __builtin_clz(m); i >= 0; i--) {
         acc = dbl(acc);
         if ((m >> i) & 1u) acc = add(acc, p);
     }

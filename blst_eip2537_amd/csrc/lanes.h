@@ -197,8 +197,9 @@ __device__ __forceinline__ Xyzz<FpI> add8c(const Xyzz<FpI> &p, const Xyzz<FpI> &
     return Xyzz<FpI>{X3, sub(pr.r0, pr.r1), ZZ3, pr.r2};
 }
 __device__ __forceinline__ Xyzz<FpI> small_mul8c(const Xyzz<FpI> &p, uint32_t m, const PairProd8 &prod) {
-    Xyzz<FpI> acc = xyzz_inf<FpI>();
-    for (int i = 31 - __builtin_clz(m | 1u); i >= 0; i--) {
+    if (m == 0) return xyzz_inf<FpI>();
+    Xyzz<FpI> acc = p;                               // the top bit: no doubling of the point at infinity
+    for (int i = 30 - __builtin_clz(m); i >= 0; i--) {
         acc = dbl8c(acc, prod);
         if ((m >> i) & 1u) acc = add8c(acc, p, prod);
     }

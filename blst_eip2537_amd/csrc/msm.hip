@@ -994,8 +994,9 @@ template <class T> __device__ __forceinline__ Xyzz<T> dbl4(const Xyzz<T> &p, int
     return Xyzz<T>{X3, sub(t0, t1), ZZ3, ZZZ3};
 }
 template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &p, uint32_t m, int r, int gb) {
-    Xyzz<T> acc = xyzz_inf<T>();
-    for (int i = 31 - __builtin_clz(m | 1u); i >= 0; i--) {
+    if (m == 0) return xyzz_inf<T>();
+    Xyzz<T> acc = p;                                 // the top bit: no doubling of the point at infinity (three rounds of products on zeros)
+    for (int i = 30 - __builtin_clz(m); i >= 0; i--) {
         acc = dbl4(acc, r, gb);
         if ((m >> i) & 1u) acc = add4(acc, p, r, gb);
     }
