@@ -284,8 +284,9 @@ static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit cou
 
 __global__ void __launch_bounds__(1024)
 k_msm_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-           uint32_t *__restrict__ hist16, uint32_t slice0) {
+           uint32_t *__restrict__ hist16, uint32_t slice0, const uint32_t *__restrict__ only_if = nullptr) {
     __shared__ uint32_t h[kLdsWords];
+    if (only_if && !*only_if) return;                 // the partitioned sort took this plan (k_sort_*): nothing to do
     const uint32_t slice = slice0 + blockIdx.x, w = blockIdx.y;
     const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
     const uint32_t words = (nbw + 1u) / 2u;
@@ -303,7 +304,8 @@ k_msm_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, ui
 
 __global__ void __launch_bounds__(256)
 k_msm_slicescan(const uint32_t *__restrict__ hist16, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-                uint32_t *__restrict__ base, uint32_t *__restrict__ counts) {
+                uint32_t *__restrict__ base, uint32_t *__restrict__ counts, const uint32_t *__restrict__ only_if = nullptr) {
+    if (only_if && !*only_if) return;
     // one thread per packed pair of buckets of one window
     const uint32_t w = blockIdx.y, pair = blockIdx.x * 256u + threadIdx.x;
     const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
@@ -323,8 +325,10 @@ k_msm_slicescan(const uint32_t *__restrict__ hist16, MsmPlan pl, uint32_t nslice
 
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries, uint32_t passes) {
+              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries, uint32_t passes,
+              const uint32_t *__restrict__ only_if = nullptr) {
     __shared__ uint32_t h[kLdsWords];
+    if (only_if && !*only_if) return;
     // XCD-aware block order (speed only): blocks are dealt round-robin over the 8 XCDs, so block ids
     // with equal id % 8 share an L2.  All slices of a window go to one such group: the window's
     // entries region (4 B x n, 4 MB at 2^20) is then filled from one L2, where the 4-byte stores of
@@ -372,11 +376,17 @@ k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices,
 //   k_sort_fine            [partition x window]  the partition's run (~4 096 entries) counted and ranked over its 128
 //                                            buckets in LDS, written out in bucket order; per-bucket counts
 // Entry positions equal the exclusive scan of the counts in bucket order, so the scan / task kernels run unchanged.
-static constexpr uint32_t kFineBits = 7, kFine = 1u << kFineBits, kMaxParts = 512;
+// Degenerate inputs: k_sort_fine gives a partition to ONE block, so a partition that holds most of a window (all scalars equal:
+// every record of a window in one bucket) would serialise hundreds of thousands of LDS atomics on one address (2^18 equal
+// scalars: +0.8 ms).  k_sort_coarse_scan therefore raises a flag when a partition exceeds four times its window's mean; the
+// partitioned kernels after it then do nothing and the direct-scatter kernels, launched behind them with the flag as their
+// condition, take the plan (they spread a heavy bucket over its 32 768-record slices).  Ordinary inputs pay three empty launches.
+static constexpr uint32_t kFineBits = 7, kFine = 1u << kFineBits, kMaxParts = 512, kHeavyFactor = 4;
 __global__ void __launch_bounds__(1024)
-k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ chist) {
+k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ chist, uint32_t *__restrict__ heavy) {
     __shared__ uint32_t h[kMaxParts];
     const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    if (slice == 0 && w == 0 && threadIdx.x == 0) *heavy = 0;        // raised by k_sort_coarse_scan (next launch)
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
     if (threadIdx.x < kMaxParts) h[threadIdx.x] = 0;
     __syncthreads();
@@ -389,7 +399,7 @@ k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nsl
     if (threadIdx.x < parts) chist[((size_t)w * kMaxParts + threadIdx.x) * nslices + slice] = h[threadIdx.x];
 }
 __global__ void __launch_bounds__(1024)
-k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ wtotal) {
+k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ wtotal, uint32_t *__restrict__ heavy) {
     __shared__ uint32_t sm[1024];
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
@@ -409,6 +419,13 @@ k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, u
     uint32_t run = sm[t] - sum;                                  // exclusive
     for (uint32_t k = a; k < b; k++) { const uint32_t v = row[k]; row[k] = run; run += v; }
     if (t == 1023u) wtotal[w] = sm[t];
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t total = sm[1023], limit = kHeavyFactor * (total / parts) + 4096u;
+    for (uint32_t p = t; p < parts; p += 1024u) {
+        const uint32_t size = (p + 1u < parts ? row[(size_t)(p + 1u) * nslices] : total) - row[(size_t)p * nslices];
+        if (size > limit) atomicOr(heavy, 1u);
+    }
 }
 __global__ void __launch_bounds__(64)
 k_sort_window_bases(const uint32_t *__restrict__ wtotal, int W, uint32_t *__restrict__ wbase) {
@@ -423,8 +440,9 @@ k_sort_window_bases(const uint32_t *__restrict__ wtotal, int W, uint32_t *__rest
 static constexpr uint32_t kStageEntries = kSlice;                // a slice's entries staged in LDS: 128 KB
 __global__ void __launch_bounds__(1024)
 k_sort_coarse_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
-                      const uint32_t *__restrict__ wbase, uint32_t *__restrict__ centries) {
+                      const uint32_t *__restrict__ wbase, uint32_t *__restrict__ centries, const uint32_t *__restrict__ heavy) {
     __shared__ uint32_t cnt[kMaxParts], start[kMaxParts + 1], stage[kStageEntries];
+    if (*heavy) return;
     const uint32_t slice = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
     if (t < kMaxParts) cnt[t] = 0;
@@ -468,8 +486,9 @@ k_sort_coarse_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t 
 static constexpr uint32_t kFineStage = 16384;                    // entries of a partition staged in LDS (4x the mean at 2^20)
 __global__ void __launch_bounds__(512)
 k_sort_fine(const uint32_t *__restrict__ centries, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
-            const uint32_t *__restrict__ wbase, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts) {
+            const uint32_t *__restrict__ wbase, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, const uint32_t *__restrict__ heavy) {
     __shared__ uint32_t fh[kFine], fstart[kFine + 1], stage[kFineStage];
+    if (*heavy) return;
     const uint32_t part = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
     if (part >= parts) return;
@@ -1454,20 +1473,18 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     static const bool env_sort2 = [] { const char *v = getenv("EIP2537_SORT2"); return !v || atoi(v) != 0; }();
     const bool sort2 = env_sort2 && pl.c == 16 && n < (1u << 24) && (pl.B % kFine) == 0 && (pl.BT % kFine) == 0 &&
                        (std::max(pl.B, pl.BT) >> kFineBits) <= kMaxParts && pl.W < 64;
-    if (sort2) {
-        HIPCHK(e->hist16.reserve((size_t)pl.W * kMaxParts * nslices * 4));            // partition counts [W][parts][slices]
-        HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * n * 4, rc_bytes)));      // entries in partition order; later the row / column sums
-    } else {
-        HIPCHK(e->hist16.reserve((size_t)pl.W * nslices * (nbmax / 2) * 4));          // hist16 [W][slices][nbmax] (packed)
-        HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * nslices * nbmax * 4, rc_bytes)));   // base [W][slices][nbmax]; after the scatter: the row / column sums
-    }
+    // hist16: [W][slices][nbmax] packed slice histograms (direct scatter) | [W][parts][slices] partition counts (partitioned sort);
+    // slice_base: [W][slices][nbmax] prefix over the slices | the entries in partition order; later the row / column sums.
+    // A sort2 plan keeps room for both forms: a degenerate input is handed to the direct scatter on the device (kHeavyFactor).
+    HIPCHK(e->hist16.reserve(std::max((size_t)pl.W * nslices * (nbmax / 2) * 4, sort2 ? (size_t)pl.W * kMaxParts * nslices * 4 : (size_t)0)));
+    HIPCHK(e->slice_base.reserve(std::max(std::max((size_t)pl.W * nslices * nbmax * 4, sort2 ? (size_t)pl.W * n * 4 : (size_t)0), rc_bytes)));
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve(pl.max_entries * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4 + 2 * 64 * 4));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges + window totals / bases
+    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4 + 2 * 64 * 4 + 16));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges + window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
@@ -1537,14 +1554,18 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     e->host_src = nullptr;
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
+    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260, *heavy = nullptr;
     if (sort2) {
         uint32_t *wtotal = blk + 2048 + 264, *wbase = wtotal + 64;
-        hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16);
-        hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, pl, nslices, wtotal);
+        heavy = wbase + 64;
+        hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16, heavy);
+        hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, pl, nslices, wtotal, heavy);
         hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
-        hipLaunchKernelGGL(k_sort_coarse_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16, wbase, base);
-        hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, pl, nslices, hist16, wbase, entries, counts);
+        hipLaunchKernelGGL(k_sort_coarse_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+        hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, pl, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
+        // the direct scatter, only when the flag is up (degenerate input)
+        hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u, (const uint32_t *)heavy);
+        hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts, (const uint32_t *)heavy);
     } else {
         hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     }
@@ -1554,8 +1575,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    if (!sort2)
-        hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
+    if (!sort2 || heavy)
+        hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes,
+                           (const uint32_t *)heavy);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2, lenhist, gshift, split_g);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
