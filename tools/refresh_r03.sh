@@ -17,6 +17,7 @@ step bench pairing;    timeout -k 10 400 python bench.py --workload pairing > $O
 step part 1 done
 else
 step size sweep
+rm -f $O/r03_size_sweep.txt
 for wl in "g1msm 22" "g1msm 21" "g1msm 20" "g1msm 19" "g1msm 18" "g1msm 17" "g1msm 16" "g1msm 14" "g1msm 12" "g1msm 10" "g1msm 7" "g2msm 18" "g2msm 16" "g2msm 14" "g2msm 10" "g2msm 7" "pairing 12" "pairing 10" "pairing 6" "pairing 3"; do
   set -- $wl
   timeout -k 10 200 python bench.py --workload $1 --log2n $2 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-host-abi 2>/dev/null | python -c "
