@@ -155,6 +155,16 @@ def test_heavy_buckets_top_window_and_equal_scalars(X, clib):
         # the partitioned sort of the c = 16 plans (k_sort_*): a ragged second slice (32 768 + 7 233 records), and G2
         rag = X.gen_msm_input("g1", 40001, A, B, 4001)
         assert clib.call("bls12_g1multiexp", rag) == (0, X.g1_multiexp(rag))
+        # degenerate digit patterns through the same plan: no entries at all, one entry, one bucket per window, two buckets
+        recs = [rag[i * 160:(i + 1) * 160] for i in range(40001)]
+        for name, inp in {
+            "all scalars zero": b"".join(r[:128] + bytes(32) for r in recs),
+            "all points infinity": b"".join(bytes(128) + r[128:] for r in recs),
+            "one live record": b"".join((r if i == 12345 else r[:128] + bytes(32)) for i, r in enumerate(recs)),
+            "scalars = 2^255": b"".join(r[:128] + m.encode_scalar(1 << 255) for r in recs),
+            "two values alternating": b"".join(r[:128] + m.encode_scalar((1 << 200) + 5 if i & 1 else 2 ** 256 - 3) for i, r in enumerate(recs)),
+        }.items():
+            assert call_x(X.g1_multiexp, inp) == clib.call("bls12_g1multiexp", inp), name
         g2 = X.gen_msm_input("g2", 3001, A, B, 3001)
         assert clib.call("bls12_g2multiexp", g2) == (0, X.g2_multiexp(g2))
         assert X.last_plan()["window_bits"] == 16
