@@ -524,6 +524,7 @@ k_sort_fine(const uint32_t *__restrict__ centries, MsmPlan pl, uint32_t nslices,
     }
 }
 
+static constexpr uint32_t kTaskItems = 1024;          // buckets / tasks per block of k_msm_tasks / k_msm_task_perm
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
@@ -532,10 +533,13 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
     // also the histogram of task length classes ceil(len / 2^gshift) in [1, 64] for the sort below (a
     // separate pass over the task array before: 0.03 ms at 2^20); buckets from split_g on are counted as
     // a second set (their tasks are ordered and accumulated on their own: two-level reduce)
+    // a block takes kTaskItems buckets (four per thread): its length classes reach the global counters as one atomic per class
+    // and block -- with 256 buckets per block those same-address atomics were most of the kernel's 31 us at 2^20
     __shared__ uint32_t h[130];
     if (threadIdx.x < 130) h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t j = 0; j < kTaskItems / 256u; j++) {
+    const uint32_t g = blockIdx.x * kTaskItems + j * 256u + threadIdx.x;
     const uint32_t hs = g >= split_g ? 65u : 0u;
     const uint32_t cnt = g < NB ? counts[g] : 0u;
     if (cnt) {
@@ -550,6 +554,7 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
         if (rest) tasks[t0 + full] = Task{off + (full << lshift), rest};
         if (full) atomicAdd(&h[hs + ((L + gm) >> gshift)], full);
         if (rest) atomicAdd(&h[hs + ((rest + gm) >> gshift)], 1u);
+    }
     }
     __syncthreads();
     if (threadIdx.x < 130 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
@@ -585,17 +590,26 @@ k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ tot
     __shared__ uint32_t h[130], base[130];
     if (threadIdx.x < 130) h[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    uint32_t len = 0, local = 0;
+    constexpr uint32_t kPer = kTaskItems / 256u;          // tasks per thread: one range reservation per class and block
+    uint32_t len[kPer], local[kPer];
     const uint32_t t_split = split_g == 0xffffffffu ? 0xffffffffu : taskoff[split_g];     // task ids follow the bucket order
-    if (t < totals[1]) {
-        len = ((tasks[t].len + (1u << gshift) - 1u) >> gshift) + (t >= t_split ? 65u : 0u);
-        local = atomicAdd(&h[len], 1u);
+    const uint32_t ntasks = totals[1];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++) {
+        const uint32_t t = blockIdx.x * kTaskItems + j * 256u + threadIdx.x;
+        len[j] = 0;
+        local[j] = 0;
+        if (t < ntasks) {
+            len[j] = ((tasks[t].len + (1u << gshift) - 1u) >> gshift) + (t >= t_split ? 65u : 0u);
+            local[j] = atomicAdd(&h[len[j]], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < 130 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&lenoff[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
-    if (len) perm[base[len] + local] = t;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++)
+        if (len[j]) perm[base[len[j]] + local[j]] = blockIdx.x * kTaskItems + j * 256u + threadIdx.x;
 }
 
 // product used inside the multi-lane point operations: over Fp2 optionally the fully inlined body
@@ -1578,11 +1592,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     if (!sort2 || heavy)
         hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes,
                            (const uint32_t *)heavy);
-    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
+    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2, lenhist, gshift, split_g);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
-    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3((pl.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
     HIPCHK(hipEventRecord(e->ev_a, s));
     if (two_level) {
         int st2 = launch_two_level(e, pl, n, lshift, task_blocks, red_blocks, split_g, ptl, entries, tasks, perm, totals, ranges, partial, taskoff,
@@ -1871,11 +1885,11 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
-    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + 255u) / 256u), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
+    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
                        split_small, split_big, totals + 2, lenhist, gshift, 0xffffffffu);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
     hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
-    hipLaunchKernelGGL(k_msm_task_perm, dim3(task_blocks), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, 0xffffffffu);
+    hipLaunchKernelGGL(k_msm_task_perm, dim3((pl.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, 0xffffffffu);
     HIPCHK(hipEventRecord(e->ev_a, s));
     launch_accum(s, task_blocks, true, pts, ptl, entries, tasks, perm, totals, partial);          // two lanes per task
     HIPCHK(hipEventRecord(e->ev_b, s));
