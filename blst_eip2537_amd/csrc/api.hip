@@ -13,6 +13,8 @@
 // without a working HIP device they fail loudly with EIP2537_MEMORY_ERROR.
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdio.h>
@@ -20,6 +22,7 @@
 #include <string.h>
 #include <algorithm>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #include "codec.h"
 #include "pairing.h"
@@ -214,6 +217,7 @@ static void slot_reset(Engine &e) {
     (void)hipGetLastError();
     for (hipStream_t *s : {&e.stream, &e.stream2, &e.stream3}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     for (hipEvent_t *v : {&e.ev_start, &e.ev_stop, &e.ev_a, &e.ev_b, &e.ev_j2, &e.ev_j3, &e.ev_c}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
+    for (hipEvent_t &v : e.ev_copy) { if (v) (void)hipEventDestroy(v); v = nullptr; }
     e.release_workspace();
     e.ready = false;
     e.failed = false;
@@ -347,7 +351,8 @@ template <> int msm_dispatch<Fp2>(Engine *e, const void *d_in, size_t n, uint32_
 // One device pipeline on pool `pi` (-1: least busy listed device).  device_input: `in` is already in
 // HBM on that pool's device; want_partial: write the projective partial instead of the encoding.
 template <class F>
-static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_input, bool want_partial, CopyGate *gate = nullptr, int turn = 0) {
+static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_input, bool want_partial, CopyGate *gate = nullptr, int turn = 0,
+                     const ShardFeed *feed = nullptr) {
     // a shard of a pipelined call takes its engine slot only when it is its turn to copy: a slot holder never waits for another
     // shard, so concurrent pipelined calls cannot starve each other of slots
     if (gate) gate->wait_turn(turn);
@@ -365,12 +370,14 @@ static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_in
         e->host_src = in;
         e->copy_gate = gate;
         e->copy_turn = turn;
+        if (feed) e->feed = *feed;                  // staged shard by shard into one bucket space (msm.hip)
         d_in = e->input.p;
     }
     Xyzz<F> acc;
     int st = msm_dispatch<F>(e, d_in, n, reinterpret_cast<uint32_t *>(&acc));
     e->host_src = nullptr;                      // never retained past the call (an early error return leaves it set)
     e->copy_gate = nullptr;
+    e->feed.k = 0;
     if (st) return st;
     if (want_partial) {
         memcpy(out, &acc, sizeof acc);
@@ -619,24 +626,68 @@ static std::vector<int> split_plan(size_t n, size_t min_per_shard) {
     }
     return pools;
 }
-// run fn(shard) for every shard, shard 0 on the calling thread
-template <class Fn> static void run_shards(size_t shards, Fn &&fn) {
-    std::vector<std::thread> th;
-    std::vector<CallStats> stats(shards);
-    th.reserve(shards);
-    size_t started = 1;
-    for (; started < shards; started++) {
-        const size_t s = started;
-        try {
-            th.emplace_back([&, s] { fn(s); stats[s] = t_last; });
-        } catch (...) {                            // no more threads: the remaining shards run on this thread, in order
-            break;
+// Persistent worker threads for the shards of split calls (round 4: round 3 created and joined std::threads inside every such
+// call).  A job never waits in the queue: post() starts another worker whenever no idle one is left (up to kMaxWorkers; beyond
+// that it refuses and the caller runs the shard itself).  Leaked on purpose: workers sleep on its condition variable until the
+// process ends.
+class Workers {
+    static constexpr int kMaxWorkers = 64;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    int idle = 0, total = 0;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            idle++;
+            cv.wait(lk, [&] { return !q.empty(); });
+            idle--;
+            std::function<void()> f = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            f();
+            lk.lock();
         }
+    }
+public:
+    bool post(std::function<void()> f) {
+        std::lock_guard<std::mutex> lk(m);
+        if ((int)q.size() >= idle) {                 // every idle worker already has a job coming
+            if (total >= kMaxWorkers) return false;
+            try { std::thread([this] { loop(); }).detach(); } catch (...) { return false; }
+            total++;
+        }
+        q.push_back(std::move(f));
+        cv.notify_one();
+        return true;
+    }
+    static Workers &get() { static Workers *w = new Workers; return *w; }
+};
+// run fn(shard) for every shard, shard 0 on the calling thread, the others on the persistent workers
+template <class Fn> static void run_shards(size_t shards, Fn &&fn) {
+    std::vector<CallStats> stats(shards);
+    std::mutex dm;
+    std::condition_variable dcv;
+    size_t pending = 0;
+    std::vector<size_t> mine;                      // shards no worker could take: they run here, in order, BEFORE shard 0 returns
+    for (size_t s = 1; s < shards; s++) {
+        { std::lock_guard<std::mutex> lk(dm); pending++; }
+        const bool ok = Workers::get().post([&, s] {
+            try { fn(s); } catch (...) {}
+            stats[s] = t_last;
+            std::lock_guard<std::mutex> lk(dm);
+            pending--;
+            dcv.notify_all();
+        });
+        if (!ok) { { std::lock_guard<std::mutex> lk(dm); pending--; } mine.push_back(s); }
     }
     fn(0);
     stats[0] = t_last;
-    for (size_t s = started; s < shards; s++) { fn(s); stats[s] = t_last; }
-    for (auto &t : th) t.join();
+    for (size_t s : mine) { fn(s); stats[s] = t_last; }
+    {
+        std::unique_lock<std::mutex> lk(dm);
+        dcv.wait(lk, [&] { return pending == 0; });
+    }
     // the call's timing is that of its slowest shard
     for (size_t s = 1; s < shards; s++)
         if (stats[s].valid && stats[s].pipeline_ms > t_last.pipeline_ms) t_last = stats[s];
@@ -651,12 +702,62 @@ template <class Fn> static void run_shards(size_t shards, Fn &&fn) {
 // EIP2537_H2D_PIPELINE=0: one copy, one pipeline; k >= 2: k shards whatever the size (A/B).
 template <class F> static size_t pipeline_shards(size_t n) {
     static const int mode = [] { const char *v = getenv("EIP2537_H2D_PIPELINE"); return v ? atoi(v) : 1; }();
-    const size_t cap = std::min<size_t>(6, (size_t)g_nslots);
-    if (mode >= 2) return n >= (size_t)1024 * (size_t)mode ? (size_t)mode : 1;
+    size_t cap;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        cap = std::min<size_t>(6, (size_t)g_nslots);
+    }
     if (mode == 0 || g_window_override.load() != 0) return 1;
+    if (mode >= 2) return n >= (size_t)1024 * (size_t)mode ? std::min(cap, (size_t)mode) : 1;
     const bool g1 = sizeof(F) == sizeof(Fp);
     if (n < (g1 ? (size_t)1 << 19 : (size_t)1 << 18)) return 1;
     return std::min(cap, std::max<size_t>(2, g1 ? n / 349525 : n >> 17));
+}
+// Record shards of a staged G1 call (round 4; msm.hip runs them: the shards share one bucket space, so only the LAST shard's
+// decode / sort / accumulate and one bucket reduce follow the last byte of the copy).  A small first shard starts the device after
+// ~0.2 ms of copy instead of ~1 ms; the rest are equal shards of about 2^18 records -- below that a shard's sort and task kernels
+// (which visit all 557 056 buckets whatever the shard holds) stop paying for the overlap (profiles/r04_h2d_stages.txt).
+// $EIP2537_H2D_STAGES: "k" = k equal shards, or a comma list of relative shard weights (A/B); EIP2537_H2D_PIPELINE=0: one copy.
+static ShardFeed stage_plan_g1(size_t n) {
+    ShardFeed f;
+    static const int mode = [] { const char *v = getenv("EIP2537_H2D_PIPELINE"); return v ? atoi(v) : 1; }();
+    static const std::vector<uint32_t> env = [] {
+        std::vector<uint32_t> w;
+        if (const char *v = getenv("EIP2537_H2D_STAGES"))
+            for (const char *c = v; *c;) {
+                char *endp = nullptr;
+                const unsigned long x = strtoul(c, &endp, 10);
+                if (endp == c) break;
+                w.push_back((uint32_t)x);
+                c = *endp == ',' ? endp + 1 : endp;
+            }
+        return w;
+    }();
+    if (mode == 0 || g_window_override.load() != 0 || n >= ((size_t)1 << 31)) return f;
+    // (only the c = 16 plans, n > 2^17, share buckets: msm.hip takes any other call in one copy whatever is asked for here)
+    std::vector<uint64_t> w;
+    if (env.size() == 1) w.assign(std::min<size_t>(env[0], ShardFeed::kMax), 1u);
+    else if (env.size() > 1) w.assign(env.begin(), env.begin() + std::min<size_t>(env.size(), ShardFeed::kMax));
+    else {
+        if (n < ((size_t)1 << 19)) return f;
+        const size_t first = (size_t)1 << 16;
+        const size_t rest = std::min<size_t>(ShardFeed::kMax - 1, std::max<size_t>(1, (n - first + ((size_t)1 << 17)) >> 18));
+        w.push_back(first);
+        for (size_t i = 0; i < rest; i++) w.push_back((n - first) / rest);
+    }
+    uint64_t total = 0;
+    for (uint64_t x : w) total += x;
+    if (w.size() < 2 || !total) return f;
+    uint64_t run = 0;
+    f.bound[0] = 0;
+    int k = 0;
+    for (size_t i = 0; i < w.size(); i++) {
+        run += w[i];
+        const uint32_t b = i + 1 == w.size() ? (uint32_t)n : (uint32_t)((unsigned __int128)n * run / total);
+        if (b > f.bound[k]) f.bound[++k] = b;          // empty shards vanish
+    }
+    f.k = k;
+    return f;
 }
 static int least_busy_pool() {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -673,11 +774,33 @@ template <class F> static int msm_host_abi(byte *out, const byte *in, size_t in_
     if (host_route(n, HostMax<F>::kUnits)) return device_present() ? msm_host_small<F>(out, in, n) : E_MEMORY_ERROR;
     if (n >= CoalesceCfg<F>::kMinRecords && n <= CoalesceCfg<F>::kMaxRecords && coalesce_enabled() && g_window_override.load() == 0)
         return msm_coalesced<F>(out, in, n);
-    // Record ranges: one per listed device when the input is at least two shards' worth (split_plan), and inside a device's range
-    // the pipelined shards of pipeline_shards(): the 168 MB copy of 2^20 G1 records (3.2 ms at the link's ~53 GB/s) is as long as
-    // the whole device pipeline and a sum over records can be cut anywhere, so a range is cut into 2 .. 6 contiguous shards on
-    // engine slots of the SAME device whose copies follow each other (CopyGate, one per device) while the earlier shards compute.
+    // Record ranges: one per listed device when the input is at least two shards' worth (split_plan); inside a device's range the
+    // copy is hidden behind compute -- the 168 MB copy of 2^20 G1 records (3.2 ms at the link's ~53 GB/s) is as long as the whole
+    // device pipeline and a sum over records can be cut anywhere.
     std::vector<int> pools = split_plan(n, SplitMin<F>::kRecords);
+    if (std::is_same<F, Fp>::value) {
+        // G1: a device's range is STAGED (stage_plan_g1: record shards copied back to back by the slot's helper thread, decoded /
+        // sorted / accumulated behind their own copy into one shared bucket space; one bucket reduce, one host tail: msm.hip)
+        if (pools.empty()) {
+            const ShardFeed feed = stage_plan_g1(n);
+            return msm_entry<F>(-1, out, in, n, false, false, nullptr, 0, &feed);
+        }
+        const size_t shards = pools.size();
+        std::vector<Xyzz<F>> parts(shards);
+        std::vector<int> rc(shards, E_MEMORY_ERROR);
+        run_shards(shards, [&](size_t s) {
+            const size_t lo = n * s / shards, hi = n * (s + 1) / shards;
+            const ShardFeed feed = stage_plan_g1(hi - lo);
+            rc[s] = msm_entry<F>(pools[s], reinterpret_cast<byte *>(&parts[s]), in + lo * rec, hi - lo, false, true, nullptr, 0, &feed);
+        });
+        for (size_t s = 0; s < shards; s++)
+            if (rc[s]) return rc[s];
+        Xyzz<F> acc = parts[0];
+        for (size_t s = 1; s < shards; s++) acc = add(acc, parts[s]);
+        host_encode_point<F>(out, to_affine(acc));
+        return E_SUCCESS;
+    }
+    // G2 (c <= 13 plans up to 2^18 records: no shared bucket space): the round-3 form, independent shard pipelines
     if (pools.empty()) {
         if (pipeline_shards<F>(n) < 2) return msm_entry<F>(-1, out, in, n, false, false);
         const int pi = least_busy_pool();
@@ -1041,6 +1164,11 @@ API int eip2537_hip_last_plan(char *kernel_name, size_t cap, int *window_bits, i
     if (units) *units = c.plan.units;
     if (buckets) *buckets = c.plan.buckets;
     return 0;
+}
+API int eip2537_hip_last_shards(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const CallStats &c = t_last.valid ? t_last : g_last;
+    return c.valid ? c.plan.shards : 0;
 }
 // Release the workspace of every idle engine slot that holds more than keep_bytes (slots grow to the
 // largest call they have served: ~0.9 GB after one 2^20-record MSM).  Returns the bytes released.

@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 namespace eip {
 
@@ -26,7 +28,14 @@ struct LastPlan {
     int lanes;         // lanes per task / pair of the dominant kernel
     uint32_t units;    // records / pairs of the launch
     uint32_t buckets;  // MSM buckets (0 for a pairing batch)
+    int shards;        // record shards the call was staged in (1: one copy / resident input)
 };
+
+// Compute units / SIMDs of a device, read once per device from hipGetDeviceProperties (msm.hip).  The chain-bound kernels size
+// their grids to "one wave per SIMD"; nothing assumes the full 256-CU part any more (a CPX partition or a CU mask reports
+// fewer).  $EIP2537_HIP_CUS overrides the count (tests).
+struct ChipShape { uint32_t cus, simds; };
+ChipShape chip_shape(int device);
 
 // Order of the host -> device copies of the shards of ONE host-input call that share a device (api.hip, msm_host_abi):
 // shard s stages its records only after shard s - 1 has handed its own to the copy engine, so that the shards' pipelines
@@ -48,12 +57,125 @@ struct CopyGate {
     }
 };
 
+// One persistent helper thread per engine slot, started by the slot's first staged call (round 4: no thread is created per
+// call).  run() hands it one job; wait() returns when that job has finished.  The owner of the slot is the only caller.
+class Helper {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || (busy && job); });
+            if (quit) return;
+            std::function<void()> f;
+            f.swap(job);
+            lk.unlock();
+            f();
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+public:
+    Helper() = default;
+    Helper(const Helper &) = delete;
+    Helper &operator=(const Helper &) = delete;
+    bool run(std::function<void()> f) {                // false: no thread could be started (the caller does the work itself)
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) {
+            try { th = std::thread([this] { loop(); }); } catch (...) { return false; }
+        }
+        cv.wait(lk, [&] { return !busy; });
+        job = std::move(f);
+        busy = true;
+        cv.notify_all();
+        return true;
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !busy; });
+    }
+    ~Helper() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
+// Record ranges of a host-input call that is staged shard by shard (api.hip decides the cut, msm.hip runs it): shard s is
+// records [bound[s], bound[s + 1]).  k <= 1: one copy.
+struct ShardFeed {
+    static constexpr int kMax = 8;
+    int k = 0;
+    uint32_t bound[kMax + 1] = {};
+};
+
+// The copies of a staged call: the slot's helper thread hands the shards of the caller's buffer to `copy_stream` one behind the
+// other (a pageable hipMemcpyAsync keeps its host thread until the last byte is staged, so the link never idles between shards
+// and never carries two at once) and records an event behind each; the launching thread waits for "shard s handed over" and
+// then orders that shard's kernels behind the event.  finish() returns when the helper no longer touches the caller's buffer:
+// every exit of the pipeline, early error returns included, passes through it (destructor).
+struct StagedCopy {
+    std::mutex m;
+    std::condition_variable cv;
+    int posted = 0;
+    bool failed = false;
+    Helper *helper = nullptr;
+    bool start(Helper &h, int device, hipStream_t copy_stream, hipEvent_t *events, const ShardFeed &f, size_t rec_bytes, void *dst, const void *src) {
+        helper = &h;
+        const ShardFeed feed = f;
+        const bool ok = h.run([this, device, copy_stream, events, feed, rec_bytes, dst, src] {
+            bool bad = hipSetDevice(device) != hipSuccess;
+            for (int s = 0; s < feed.k; s++) {
+                if (!bad) {
+                    const size_t off = (size_t)feed.bound[s] * rec_bytes, len = (size_t)(feed.bound[s + 1] - feed.bound[s]) * rec_bytes;
+                    bad = hipMemcpyAsync(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+                          hipEventRecord(events[s], copy_stream) != hipSuccess;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    posted = s + 1;
+                    failed = failed || bad;
+                }
+                cv.notify_all();
+            }
+            // a pinned / registered caller buffer makes the copies truly asynchronous: the buffer must not be read after the call
+            // returns, so the helper only finishes when the copy stream has drained
+            if (hipStreamSynchronize(copy_stream) != hipSuccess) {
+                std::lock_guard<std::mutex> lk(m);
+                failed = true;
+            }
+        });
+        if (!ok) helper = nullptr;
+        return ok;
+    }
+    bool wait_shard(int s) {                          // false: a copy failed
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return posted > s; });
+        return !failed;
+    }
+    void finish() {
+        if (helper) helper->wait();
+        helper = nullptr;
+    }
+    ~StagedCopy() { finish(); }
+};
+
 struct Engine {
     bool ready = false;
     bool failed = false;   // a HIP call failed mid-pipeline: the slot is drained and rebuilt on release
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr, ev_c = nullptr;
+    hipEvent_t ev_copy[ShardFeed::kMax] = {};      // behind the copy of every shard of a staged host-input call (stream2)
+    Helper helper;                                 // stages those copies
+    ShardFeed feed;                                // set with host_src by a staged call (k > 1)
     // staging + per-call workspace (grow-only)
     DevBuf input;          // H2D copy of a host caller's records
     CopyGate *copy_gate = nullptr;    // set with host_src by a shard of a pipelined host-input call
@@ -71,6 +193,9 @@ struct Engine {
     DevBuf tasks, perm;    // <= L-entry runs of one bucket; tasks ordered by length
     DevBuf split_lists;    // buckets split into several tasks: lightly | heavily
     DevBuf partial;        // one XYZZ point per task        (pairing: the 68 x k line records)
+    DevBuf bacc;           // G1 c = 16 plans: one limb-form XYZZ running sum per bucket, over all record shards of the call
+    DevBuf taskbkt;        // task -> bucket << 1 | first task of its bucket
+    DevBuf rcsum;          // row / column sums of the two-level reduce
     DevBuf winout;         // per (window, reduce block) sums (pairing: per-block / per-step Fp12 products)
     // last-call kernel timing (ms), filled when timing is enabled
     float last_kernel_ms = 0.f;   // whole device pipeline of the last call
@@ -80,7 +205,7 @@ struct Engine {
 
     template <class Fn> void for_each_buf(Fn &&fn) {
         for (DevBuf *b : {&input, &misc, &pts, &digits, &hist16, &slice_base, &counts, &offsets, &taskoff, &scan_blk,
-                          &entries, &tasks, &perm, &split_lists, &partial, &winout}) fn(*b);
+                          &entries, &tasks, &perm, &split_lists, &partial, &winout, &bacc, &taskbkt, &rcsum}) fn(*b);
     }
     size_t workspace_bytes() { size_t t = 0; for_each_buf([&](DevBuf &b) { t += b.cap; }); return t; }
     void release_workspace() { for_each_buf([](DevBuf &b) { b.release(); }); }

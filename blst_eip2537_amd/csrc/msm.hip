@@ -19,6 +19,7 @@
 //                            G2 spreads every point operation over 4 lanes (k_msm_reduce4)
 //   host                     adds the few per-block points of each window, Horner over windows
 #include <algorithm>
+#include <mutex>
 #include <stdio.h>
 #include <type_traits>
 #include <vector>
@@ -41,6 +42,27 @@ namespace eip {
     } while (0)
 
 struct Task { uint32_t start, len; };
+
+ChipShape chip_shape(int device) {
+    static std::mutex mu;
+    static ChipShape cache[64];
+    std::lock_guard<std::mutex> lk(mu);
+    const int slot = device >= 0 && device < 64 ? device : 0;
+    if (!cache[slot].cus) {
+        uint32_t cus = 0;
+        if (const char *v = getenv("EIP2537_HIP_CUS")) cus = (uint32_t)atoi(v);
+        if (!cus) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = (uint32_t)prop.multiProcessorCount;
+            else { (void)hipGetLastError(); cus = 256u; }
+        }
+        cus = std::min(std::max(cus, 8u), 1024u);
+        cache[slot] = ChipShape{cus, 4u * cus};
+        if (cus != 256u)
+            fprintf(stderr, "[eip2537_hip] note: device %d has %u compute units (launch shapes were tuned on the 256 of a whole MI355X)\n", device, cus);
+    }
+    return cache[slot];
+}
 
 // Window width measured best per size class on MI355X (profiles/r01_window_sweep.txt).  The work
 // model below (products per record-window and per bucket) ranks plans well once the kernels are
@@ -181,9 +203,10 @@ __device__ __forceinline__ int decode_point_limbs(PtL *dst, const uint32_t *w, b
 template <class F>
 __global__ void __launch_bounds__(256)
 k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts, PtL *__restrict__ ptl,
-             uint32_t *__restrict__ digits, unsigned long long *err, uint32_t rec0, uint32_t rec1) {
-    const uint32_t i = rec0 + blockIdx.x * 256u + threadIdx.x;       // records [rec0, rec1): a host input arrives in chunks
-    if (i >= rec1) return;
+             uint32_t *__restrict__ digits, unsigned long long *err, uint32_t err_base) {
+    // pl.n records at `in`: a whole call, or one record shard of a staged call -- err_base is then the shard's first record, so
+    // that the error word still orders bad records by their index in the CALL
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool live = false;
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < pl.n) {
@@ -199,7 +222,7 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
                 live = true;
             }
         }
-        if (st != E_SUCCESS) atomicMin(err, ((unsigned long long)i << 3) | (unsigned long long)st);
+        if (st != E_SUCCESS) atomicMin(err, ((unsigned long long)(err_base + i) << 3) | (unsigned long long)st);
         else if (live) decode_scalar(k, w + Wire<F>::kPointWords);
     }
     if (i >= pl.n) return;
@@ -529,7 +552,11 @@ __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
             uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts,
-            uint32_t *__restrict__ lenhist, uint32_t gshift, uint32_t split_g) {
+            uint32_t *__restrict__ lenhist, uint32_t gshift, uint32_t split_g,
+            uint32_t *__restrict__ task_bucket = nullptr, Xyzz<FpL> *__restrict__ bacc = nullptr, uint32_t first_shard = 0u) {
+    // bucket accumulators (the c = 16 two-level plans, round 4): task_bucket[t] = bucket << 1 | "first task of its bucket" -- the
+    // accumulate adds a bucket's first task onto bacc[bucket], the running sum over the record shards of the call, instead of
+    // writing a per-task partial; the first shard marks the buckets it leaves empty as infinity (zz = 0), so bacc needs no memset
     // also the histogram of task length classes ceil(len / 2^gshift) in [1, 64] for the sort below (a
     // separate pass over the task array before: 0.03 ms at 2^20); buckets from split_g on are counted as
     // a second set (their tasks are ordered and accumulated on their own: two-level reduce)
@@ -542,9 +569,14 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
     const uint32_t g = blockIdx.x * kTaskItems + j * 256u + threadIdx.x;
     const uint32_t hs = g >= split_g ? 65u : 0u;
     const uint32_t cnt = g < NB ? counts[g] : 0u;
+    if (!cnt && bacc && first_shard && g < NB) bacc[g].zz = fpl_zero();
     if (cnt) {
         const uint32_t t0 = taskoff[g], off = offsets[g];
         const uint32_t L = 1u << lshift, gm = (1u << gshift) - 1u;
+        if (task_bucket) {
+            const uint32_t nt = (cnt + L - 1u) >> lshift;
+            for (uint32_t j = 0; j < nt; j++) task_bucket[t0 + j] = (g << 1) | (j == 0u ? 1u : 0u);
+        }
         // buckets split into several tasks are folded back into one partial before the reduce:
         // 2..8 tasks by one thread (k_msm_fold_small), more by one block (k_msm_fold_big)
         if (cnt > 8u * L) split_big[atomicAdd(&split_counts[1], 1u)] = g;
@@ -791,7 +823,8 @@ k_msm_accum(const Aff<F> *__restrict__ pts_, const uint32_t *__restrict__ entrie
 __global__ void __launch_bounds__(256)
 k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
               const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp> *__restrict__ partial_,
-              const uint32_t *__restrict__ range) {
+              const uint32_t *__restrict__ range, const uint32_t *__restrict__ task_bucket = nullptr, Xyzz<FpL> *__restrict__ bacc = nullptr,
+              uint32_t first_shard = 1u) {
     Xyzz<FpL> *__restrict__ partial = reinterpret_cast<Xyzz<FpL> *>(partial_);     // read by the <Fp, FpL> fold and reduce kernels
     // range: the slots [range[0], range[1]) of the task order (two-level reduce: the top window's upper half first); null: all
     const uint32_t slot = (range ? range[0] : 0u) + blockIdx.x * 256u + threadIdx.x;
@@ -800,12 +833,25 @@ k_msm_accum_l(const PtL *__restrict__ pts, const uint32_t *__restrict__ entries,
     const Task tk = tasks[t];
     AccL acc;
     bool inf = true;
+    // bucket accumulators: a bucket's first task continues the bucket's running sum over the earlier record shards of the call
+    // (stored points keep the standard bounds, which are the loop's own invariants) and leaves its result there
+    Xyzz<FpL> *dst = &partial[t];
+    if (task_bucket) {
+        const uint32_t tb = task_bucket[t];
+        if (tb & 1u) {
+            dst = &bacc[tb >> 1];
+            if (!first_shard) {
+                const Xyzz<FpL> b0 = *dst;
+                if (!is_zero(b0.zz)) { acc = AccL{b0.x, b0.y, b0.zz, b0.zzz}; inf = false; }
+            }
+        }
+    }
     for (uint32_t e = 0; e < tk.len; e++) {
         const uint32_t ent = entries[tk.start + e];
         const PtL *q = &pts[ent >> 1];
         madd_l(acc, inf, load_limbs(q->x), load_limbs((ent & 1u) ? q->ny : q->y));
     }
-    partial[t] = inf ? xyzz_inf<FpL>() : Xyzz<FpL>{acc.x, acc.y, acc.zz, acc.zzz};
+    *dst = inf ? xyzz_inf<FpL>() : Xyzz<FpL>{acc.x, acc.y, acc.zz, acc.zzz};
 }
 
 // ---- fold: buckets that were split into several tasks ------------------------------------------
@@ -939,26 +985,27 @@ __device__ __forceinline__ void pt_dbl(Xyzz<FpL> &r, const Xyzz<FpL> &a) { r = d
 template <class F, class T = typename AccumField<F>::T>    // T: the form the accumulate kernel wrote the partials in (G1: FpI or FpL)
 __global__ void __launch_bounds__(256)
 k_msm_fold_small(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
-                 const uint32_t *__restrict__ split_counts, uint32_t g_lo = 0u, uint32_t g_hi = 0xffffffffu) {
+                 const uint32_t *__restrict__ split_counts, uint32_t g_lo = 0u, uint32_t g_hi = 0xffffffffu, Xyzz<T> *__restrict__ bacc = nullptr) {
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
     for (uint32_t h = blockIdx.x * 256u + threadIdx.x; h < n; h += gridDim.x * 256u) {
         const uint32_t g = list[h];
         if (g < g_lo || g >= g_hi) continue;                   // two-level reduce: the buckets of one accumulate launch only
         const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
-        Xyzz<T> acc = partial[t0];
+        Xyzz<T> *first = bacc ? &bacc[g] : &partial[t0];       // bucket accumulators: the first task's sum lives in bacc[g]
+        Xyzz<T> acc = *first;
         for (uint32_t t = t0 + 1; t < t1; t++) {
             Xyzz<T> pt = partial[t];
             pt_add(acc, acc, pt);                      // inline for limb-form points, out of line otherwise
         }
-        partial[t0] = acc;
+        *first = acc;
     }
 }
 // more than 8 tasks: one block per bucket -- 256 strided serial chains, shuffle tree, LDS step
 template <class F, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256)
 k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
-               const uint32_t *__restrict__ split_counts, uint32_t g_lo = 0u, uint32_t g_hi = 0xffffffffu) {
+               const uint32_t *__restrict__ split_counts, uint32_t g_lo = 0u, uint32_t g_hi = 0xffffffffu, Xyzz<T> *__restrict__ bacc = nullptr) {
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     __shared__ Xyzz<T> sm[4];
     const uint32_t nh = split_counts[1];
@@ -969,7 +1016,7 @@ k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ task
         const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
         Xyzz<T> acc = xyzz_inf<T>();
         for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256u) {
-            Xyzz<T> pt = partial[t];
+            Xyzz<T> pt = (bacc && t == t0) ? bacc[g] : partial[t];
             pt_add(acc, acc, pt);                      // inline for limb-form points, out of line otherwise
         }
         for (int off = 32; off >= 1; off >>= 1) {
@@ -980,7 +1027,7 @@ k_msm_fold_big(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ task
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int k = 1; k < 4; k++) pt_add(acc, acc, sm[k]);
-            partial[t0] = acc;
+            if (bacc) bacc[g] = acc; else partial[t0] = acc;
         }
         __syncthreads();
     }
@@ -1250,8 +1297,9 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
 static constexpr uint32_t kRcCols = 256, kRcChain = 16;
 static constexpr uint32_t kRcRows = 128, kRcPerWindow = kRcRows + kRcCols;                 // B = 32 768 = 128 x 256
 __global__ void __launch_bounds__(256)
-k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, uint32_t B, uint32_t w0, Xyzz<FpL> *__restrict__ rc) {
-    const Xyzz<FpL> *__restrict__ partial = reinterpret_cast<const Xyzz<FpL> *>(partial_);
+k_msm_rowcol(const Xyzz<FpL> *__restrict__ bacc, uint32_t B, uint32_t w0, Xyzz<FpL> *__restrict__ rc) {
+    // round 4: the buckets' sums are read from the bucket accumulators bacc[bucket] (k_msm_accum_l / k_msm_fold_*) -- no task-offset
+    // lookup in front of every point load
     const uint32_t lanes_w = 2u * B / kRcChain;                        // lanes of a virtual window: rows + columns
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t w = w0 + t / lanes_w, local = t % lanes_w;
@@ -1262,29 +1310,12 @@ k_msm_rowcol(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__
     // row job: buckets 256 job + (sub + i lj);   column job: buckets 256 (sub + i lj) + job
     const uint32_t first = w * B + (is_row ? job * kRcCols + sub : sub * kRcCols + job);
     const uint32_t step = is_row ? lj : lj * kRcCols;
-    // bucket i's slot range is looked up two additions ahead and its point one addition ahead: with one wave per SIMD
-    // nothing else hides the two dependent loads (slot range, then the 224-byte point)
-    auto slots = [&](uint32_t i, uint32_t &t0, uint32_t &t1) {
-        const uint32_t g = first + min(i, kRcChain - 1u) * step;
-        t0 = taskoff[g];
-        t1 = taskoff[g + 1];
-    };
-    auto fetch = [&](uint32_t t0, uint32_t t1, Xyzz<FpL> &pt) {
-        if (t1 > t0) pt = partial[t0];                                  // multi-task buckets were folded into slot t0
-        else pt = xyzz_inf<FpL>();
-    };
-    Xyzz<FpL> acc, nxt;
-    uint32_t a0, a1, b0, b1;
-    slots(0, a0, a1);
-    slots(1, b0, b1);
-    fetch(a0, a1, acc);
-    fetch(b0, b1, nxt);
-    slots(2, a0, a1);
+    // bucket i + 1's point is loaded during the addition of bucket i: with one wave per SIMD nothing else hides the load
+    Xyzz<FpL> acc = bacc[first], nxt = bacc[first + step];
 #pragma unroll 1
     for (uint32_t i = 1; i < kRcChain; i++) {
         const Xyzz<FpL> cur = nxt;
-        if (i + 1 < kRcChain) fetch(a0, a1, nxt);                       // in flight during the addition below
-        slots(i + 2, a0, a1);
+        if (i + 1 < kRcChain) nxt = bacc[first + (i + 1u) * step];      // in flight during the addition below
         acc = add(acc, cur);
     }
     const int lane = threadIdx.x & 63;
@@ -1374,45 +1405,74 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const 
 }
 static constexpr bool window_sums_on_device(const Fp2 *) { return true; }
 static constexpr bool window_sums_on_device(const Fp *) { return false; }
-// Two-level reduce of a G1 c = 16 plan (k_msm_rowcol / k_msm_reduce_rc): the top window's upper half TB is accumulated, folded and
-// summed on stream3 beside the accumulate of everything else (TB's tasks finish long before the rest: 1 / 17 of the work); the
-// row / column launch on the critical path then is the 16 other virtual windows = exactly 1 024 waves.
-static int launch_two_level(Engine *e, const MsmPlan &pl, size_t n, uint32_t lshift, uint32_t task_blocks, uint32_t red_blocks, uint32_t split_g,
-                            const PtL *ptl, const uint32_t *entries, const Task *tasks, const uint32_t *perm, const uint32_t *totals,
-                            const uint32_t *ranges, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *split_small,
-                            const uint32_t *split_big, Xyzz<Fp> *winout) {
+// Two-level reduce of a G1 c = 16 plan (k_msm_rowcol / k_msm_reduce_rc), behind the accumulate of the call's LAST record shard: the top
+// window's upper half TB is accumulated, folded and summed on stream3 beside the accumulate of everything else (TB's tasks finish long
+// before the rest: 1 / 17 of the work); the row / column launch on the critical path then is the 16 other virtual windows = exactly
+// 1 024 waves.  Every bucket's sum over all shards of the call lives in bacc (k_msm_accum_l).
+struct TwoLevelArgs {
+    const PtL *ptl; const uint32_t *entries; const Task *tasks; const uint32_t *perm, *totals, *ranges; Xyzz<Fp> *partial; const uint32_t *taskoff;
+    const uint32_t *split_small, *split_big, *taskbkt; Xyzz<FpL> *bacc, *rc; Xyzz<Fp> *winout; uint32_t first_shard;
+};
+static int launch_two_level(Engine *e, const MsmPlan &pl, size_t ns, uint32_t lshift, uint32_t task_blocks, uint32_t red_blocks, uint32_t split_g,
+                            const TwoLevelArgs &a) {
     hipStream_t s = e->stream;
-    auto *rc = reinterpret_cast<Xyzz<FpL> *>(e->slice_base.p);
-    const uint32_t tb_blocks = (pl.B + (uint32_t)(n >> lshift) + 1u + 255u) / 256u;      // at most B buckets + n / L full tasks
+    const uint32_t tb_blocks = (pl.B + (uint32_t)(ns >> lshift) + 1u + 255u) / 256u;     // at most B buckets + ns / L full tasks
     const uint32_t unit_blocks = (2u * pl.B / kRcChain) / 256u;                          // blocks of one virtual window in k_msm_rowcol
     // stream3, beside the main accumulate (a launch of TB's ~770 waves alone would be a latency chain on an empty chip: 0.25 ms lost)
     hipStream_t s3 = e->stream3;
     HIPCHK(hipEventRecord(e->ev_j3, s));
     HIPCHK(hipStreamWaitEvent(s3, e->ev_j3, 0));
-    hipLaunchKernelGGL(k_msm_accum_l, dim3(tb_blocks), dim3(256), 0, s3, ptl, entries, tasks, perm, totals, partial, ranges + 2);
-    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s3, partial, taskoff, split_small, totals + 2, split_g, 0xffffffffu);
-    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s3, partial, taskoff, split_big, totals + 2, split_g, 0xffffffffu);
-    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks), dim3(256), 0, s3, (const Xyzz<Fp> *)partial, taskoff, pl.B, (uint32_t)pl.W, rc);
+    hipLaunchKernelGGL(k_msm_accum_l, dim3(tb_blocks), dim3(256), 0, s3, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, a.ranges + 2, a.taskbkt, a.bacc, a.first_shard);
+    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s3, a.partial, a.taskoff, a.split_small, a.totals + 2, split_g, 0xffffffffu, a.bacc);
+    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s3, a.partial, a.taskoff, a.split_big, a.totals + 2, split_g, 0xffffffffu, a.bacc);
+    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks), dim3(256), 0, s3, (const Xyzz<FpL> *)a.bacc, pl.B, (uint32_t)pl.W, a.rc);
     HIPCHK(hipEventRecord(e->ev_j2, s3));
-    hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial, ranges);
+    hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, a.ranges, a.taskbkt, a.bacc, a.first_shard);
     HIPCHK(hipEventRecord(e->ev_b, s));
-    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, partial, taskoff, split_small, totals + 2, 0u, split_g);
-    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, partial, taskoff, split_big, totals + 2, 0u, split_g);
-    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks * (uint32_t)pl.W), dim3(256), 0, s, (const Xyzz<Fp> *)partial, taskoff, pl.B, 0u, rc);      // 16 units: 1 024 waves
+    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, a.partial, a.taskoff, a.split_small, a.totals + 2, 0u, split_g, a.bacc);
+    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, a.partial, a.taskoff, a.split_big, a.totals + 2, 0u, split_g, a.bacc);
+    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks * (uint32_t)pl.W), dim3(256), 0, s, (const Xyzz<FpL> *)a.bacc, pl.B, 0u, a.rc);      // 16 units: 1 024 waves
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
-    hipLaunchKernelGGL(k_msm_reduce_rc, dim3(red_blocks), dim3(256), 0, s, (const Xyzz<FpL> *)rc, pl.W, winout);
+    hipLaunchKernelGGL(k_msm_reduce_rc, dim3(red_blocks), dim3(256), 0, s, (const Xyzz<FpL> *)a.rc, pl.W, a.winout);
     return E_SUCCESS;
 }
-static int launch_two_level(Engine *, const MsmPlan &, size_t, uint32_t, uint32_t, uint32_t, uint32_t, const PtL *, const uint32_t *, const Task *,
-                            const uint32_t *, const uint32_t *, const uint32_t *, Xyzz<Fp2> *, const uint32_t *, const uint32_t *, const uint32_t *,
-                            Xyzz<Fp2> *) { return E_MEMORY_ERROR; }      // (never selected for G2)
+// an earlier shard of a staged call: all its tasks in one launch, onto the bucket accumulators
+static void launch_shard_accum(hipStream_t s, uint32_t task_blocks, const TwoLevelArgs &a) {
+    hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, (const uint32_t *)nullptr, a.taskbkt, a.bacc, a.first_shard);
+    hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, a.partial, a.taskoff, a.split_small, a.totals + 2, 0u, 0xffffffffu, a.bacc);
+    hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, a.partial, a.taskoff, a.split_big, a.totals + 2, 0u, 0xffffffffu, a.bacc);
+}
+static int launch_two_level_or_shard(Engine *e, const MsmPlan &ps, size_t ns, uint32_t lshift, uint32_t task_blocks, uint32_t red_blocks, uint32_t split_g, bool last,
+                                     const PtL *ptl, const uint32_t *entries, const Task *tasks, const uint32_t *perm, const uint32_t *totals, const uint32_t *ranges,
+                                     Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *split_small, const uint32_t *split_big, const uint32_t *taskbkt,
+                                     Xyzz<FpL> *bacc, Xyzz<FpL> *rc, Xyzz<Fp> *winout, uint32_t first_shard) {
+    const TwoLevelArgs a{ptl, entries, tasks, perm, totals, ranges, partial, taskoff, split_small, split_big, taskbkt, bacc, rc, winout, first_shard};
+    if (last) return launch_two_level(e, ps, ns, lshift, task_blocks, red_blocks, split_g, a);
+    launch_shard_accum(e->stream, task_blocks, a);
+    return E_SUCCESS;
+}
+static int launch_two_level_or_shard(Engine *, const MsmPlan &, size_t, uint32_t, uint32_t, uint32_t, uint32_t, bool, const PtL *, const uint32_t *, const Task *,
+                                     const uint32_t *, const uint32_t *, const uint32_t *, Xyzz<Fp2> *, const uint32_t *, const uint32_t *, const uint32_t *,
+                                     const uint32_t *, Xyzz<FpL> *, Xyzz<FpL> *, Xyzz<Fp2> *, uint32_t) { return E_MEMORY_ERROR; }      // (never selected for G2)
 static constexpr uint32_t kFourLaneMaxBuckets = 131072;
 static constexpr uint32_t kMinTaskShift = 4;        // c <= 13: tasks of at most max(16, 2 x mean bucket load) entries
 template <class F> struct ReduceCfg { static constexpr bool kFourLane = false; static constexpr const char *kName = "eip::Fp"; };
 template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; static constexpr const char *kName = "eip::Fp2"; };
 
+// One device pipeline.  Host input (e->host_src): the pipeline stages the caller's records itself -- ONE copy in front of the
+// kernels, or, for the large G1 plans when api.hip has cut the call into record shards (e->feed, round 4), shard by shard: the slot's
+// helper thread hands the shards to the copy stream back to back (StagedCopy, engine.h) while this thread launches, behind each
+// shard's copy event, that shard's decode, sort and accumulate; the shards share ONE bucket space (bacc: every bucket's running sum
+// over the shards), so the bucket reduce and the host tail run once, behind the last shard.  The 168 MB copy of 2^20 records
+// (3.2 ms at the link's ~53 GB/s) is as long as the whole device pipeline; round 3 ran the shards as independent pipelines
+// (k sorts, k reduces over the same 557 056 buckets, k host tails: profiles/r03_h2d_pipeline.txt).
 template <class F>
 static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
+    ShardFeed feed = e->feed;                   // (a staged call's cut; consumed here whatever happens below)
+    e->feed.k = 0;
+    const void *host_src = e->host_src;
+    e->host_src = nullptr;                      // never retained past the call
+    StagedCopy staged_copy;                     // before anything that can return: its destructor waits for the helper thread
     if (n == 0 || n >= (1ull << 31)) return E_MEMORY_ERROR;
     if ((reinterpret_cast<uintptr_t>(d_in) & 3u) != 0) {
         fprintf(stderr, "[eip2537_hip] device input must be 4-byte aligned\n");
@@ -1420,21 +1480,6 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     MsmPlan pl = msm_make_plan((uint32_t)n, c_override, ReduceCfg<F>::kFourLane);
     if (pl.max_entries >= (1ull << 32)) return E_MEMORY_ERROR;
-    // task length limit L = 2^lshift: at least twice the mean bucket load so that split buckets stay
-    // the exception (they cost an extra fold pass), and at least kMinTaskShift.  Below ~2^18 records
-    // the accumulate is not throughput-bound: its time is the longest task's chain (~12 us per mixed
-    // addition), set by the few heavy buckets of the short top window (c = 13: 512 buckets holding
-    // n/512 records each), so a shorter L there trades a few fold additions for a 2-4x shorter chain.
-    // (measured, min 64 -> 16: G1 2^14 1.20 -> 0.86 ms, 2^16 1.44 -> 1.15 ms, G2 2^16 3.25 -> 2.80 ms of
-    // device time; L below twice the mean load is far worse -- the fold pass then sees most buckets)
-    // (only for the c <= 13 plans, whose short top window is the chain in question; at c = 16 the
-    // floor of 64 changes nothing for ordinary inputs and keeps one-bucket adversarial inputs at
-    // 2.7 instead of 3.8 ms for 2^18 records)
-    uint32_t lshift = pl.c <= 13 ? kMinTaskShift : 6u;
-    while (lshift < 20 && (1ull << lshift) < 2ull * n / pl.B) lshift++;
-    const uint32_t gshift = lshift > 6 ? lshift - 6 : 0;   // granularity of the 64 task-length classes
-    pl.L = 1u << lshift;
-    pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
     // reduce: a latency-bound serial chain of ~2S + 30 point operations per segment.
     //  G1: one lane per segment, 256 segments per block
     //  G2: 4 lanes per segment, 64 segments per block; the shortest chain that still places at
@@ -1451,7 +1496,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // working blocks only, so the target is close to that limit (before: a (blocks, W) grid sized for
     // the top window, half of it idle, and ~140 working blocks: 2^20 reduce 1.42 ms, S = 16).
     static const uint32_t env_rb = [] { const char *v = getenv("EIP2537_REDUCE_BLOCKS"); return v ? (uint32_t)atoi(v) : 0u; }();
-    const uint32_t block_target = env_rb ? env_rb : (four ? 232u : 250u);
+    const ChipShape chip = chip_shape(e->device);
+    const uint32_t block_target = env_rb ? env_rb : (four ? chip.cus - chip.cus * 3u / 32u : chip.cus - chip.cus / 42u);   // 232 | 250 of 256 CUs
     pl.S = std::max(four ? 1u : 2u, (pl.NB + seg_per_block * block_target - 1u) / (seg_per_block * block_target));
     ReduceGrid rg;
     uint32_t red_blocks;
@@ -1459,7 +1505,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         rg.bn = ((pl.B + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
         rg.bt = ((pl.BT + pl.S - 1) / pl.S + seg_per_block - 1u) / seg_per_block;
         red_blocks = (uint32_t)(pl.W - 1) * rg.bn + rg.bt;
-        if (red_blocks <= 256u || env_rb || pl.S >= 4096u) break;
+        if (red_blocks <= chip.cus || env_rb || pl.S >= 4096u) break;
     }
     // G1 plans run accumulate, fold and reduce in limb form (limb30.h): the decode kernel writes 168-byte
     // limb records instead of the 96-byte affine points.  EIP2537_LIMB_FORM=0: the FpI kernels.
@@ -1476,24 +1522,54 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level;      // G2: one sum per window comes back, not one per block
     const size_t nwin_out = dev_winsum ? (size_t)pl.W : red_blocks;
     const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
-    const uint32_t split_g = two_level ? (uint32_t)pl.W * pl.B : 0xffffffffu;      // first bucket of the top window's upper half
-    HIPCHK(e->pts.reserve(n * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
+    const uint32_t split_top = two_level ? (uint32_t)pl.W * pl.B : 0xffffffffu;      // first bucket of the top window's upper half
+
+    // Record shards: [bound[s], bound[s + 1]).  Only a two-level plan can share its buckets between shards; anything else takes
+    // the caller's buffer in one copy.
+    const bool staged = two_level && host_src && feed.k > 1 && feed.k <= ShardFeed::kMax && feed.bound[0] == 0u && feed.bound[feed.k] == (uint32_t)n;
+    if (!staged) { feed.k = 1; feed.bound[0] = 0u; feed.bound[1] = (uint32_t)n; }
+    const int K = feed.k;
+    // task length limit L = 2^lshift: at least twice the mean bucket load so that split buckets stay
+    // the exception (they cost an extra fold pass), and at least kMinTaskShift.  Below ~2^18 records
+    // the accumulate is not throughput-bound: its time is the longest task's chain (~12 us per mixed
+    // addition), set by the few heavy buckets of the short top window (c = 13: 512 buckets holding
+    // n/512 records each), so a shorter L there trades a few fold additions for a 2-4x shorter chain.
+    // (measured, min 64 -> 16: G1 2^14 1.20 -> 0.86 ms, 2^16 1.44 -> 1.15 ms, G2 2^16 3.25 -> 2.80 ms of
+    // device time; L below twice the mean load is far worse -- the fold pass then sees most buckets)
+    // (only for the c <= 13 plans, whose short top window is the chain in question; at c = 16 the
+    // floor of 64 changes nothing for ordinary inputs and keeps one-bucket adversarial inputs at
+    // 2.7 instead of 3.8 ms for 2^18 records)
+    auto shift_for = [&](uint32_t ns) {
+        uint32_t l = pl.c <= 13 ? kMinTaskShift : 6u;
+        while (l < 20 && (1ull << l) < 2ull * ns / pl.B) l++;
+        return l;
+    };
+    uint32_t ns_max = 0, max_tasks = 0;
+    for (int sh = 0; sh < K; sh++) {
+        if (feed.bound[sh + 1] <= feed.bound[sh]) return E_MEMORY_ERROR;
+        const uint32_t ns = feed.bound[sh + 1] - feed.bound[sh];
+        ns_max = std::max(ns_max, ns);
+        max_tasks = std::max(max_tasks, (uint32_t)(pl.NB + (((uint64_t)ns * pl.W) >> shift_for(ns)) + 1u));
+    }
+    pl.L = 1u << shift_for(ns_max);
+    pl.max_tasks = max_tasks;
+    HIPCHK(e->pts.reserve((size_t)ns_max * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
-    const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
+    const uint32_t nslices_max = (uint32_t)(((size_t)ns_max + kSlice - 1) / kSlice);
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
-    HIPCHK(e->digits.reserve((size_t)pl.W * n * 4));                               // digits [W][n]
+    HIPCHK(e->digits.reserve((size_t)pl.W * ns_max * 4));                          // digits [W][ns]
     // c = 16 plans below 2^24 records: the partitioned sort (k_sort_*); EIP2537_SORT2=0 or any other plan: direct scatter
     static const bool env_sort2 = [] { const char *v = getenv("EIP2537_SORT2"); return !v || atoi(v) != 0; }();
-    const bool sort2 = env_sort2 && pl.c == 16 && n < (1u << 24) && (pl.B % kFine) == 0 && (pl.BT % kFine) == 0 &&
+    const bool sort2 = env_sort2 && pl.c == 16 && ns_max < (1u << 24) && (pl.B % kFine) == 0 && (pl.BT % kFine) == 0 &&
                        (std::max(pl.B, pl.BT) >> kFineBits) <= kMaxParts && pl.W < 64;
     // hist16: [W][slices][nbmax] packed slice histograms (direct scatter) | [W][parts][slices] partition counts (partitioned sort);
-    // slice_base: [W][slices][nbmax] prefix over the slices | the entries in partition order; later the row / column sums.
+    // slice_base: [W][slices][nbmax] prefix over the slices | the entries in partition order.
     // A sort2 plan keeps room for both forms: a degenerate input is handed to the direct scatter on the device (kHeavyFactor).
-    HIPCHK(e->hist16.reserve(std::max((size_t)pl.W * nslices * (nbmax / 2) * 4, sort2 ? (size_t)pl.W * kMaxParts * nslices * 4 : (size_t)0)));
-    HIPCHK(e->slice_base.reserve(std::max(std::max((size_t)pl.W * nslices * nbmax * 4, sort2 ? (size_t)pl.W * n * 4 : (size_t)0), rc_bytes)));
+    HIPCHK(e->hist16.reserve(std::max((size_t)pl.W * nslices_max * (nbmax / 2) * 4, sort2 ? (size_t)pl.W * kMaxParts * nslices_max * 4 : (size_t)0)));
+    HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * nslices_max * nbmax * 4, sort2 ? (size_t)pl.W * ns_max * 4 : (size_t)0)));
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
-    HIPCHK(e->entries.reserve(pl.max_entries * 4));
+    HIPCHK(e->entries.reserve((size_t)pl.W * ns_max * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>)));
@@ -1501,18 +1577,20 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4 + 2 * 64 * 4 + 16));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges + window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
+    if (two_level) {
+        HIPCHK(e->bacc.reserve((size_t)pl.NB * sizeof(Xyzz<FpL>)));
+        HIPCHK(e->taskbkt.reserve((size_t)pl.max_tasks * 4));
+        HIPCHK(e->rcsum.reserve(rc_bytes));
+    }
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
 
     static const uint32_t env_sp = [] { const char *v = getenv("EIP2537_SCATTER_PASSES"); return v ? (uint32_t)atoi(v) : 0u; }();
-    const uint32_t scatter_passes = env_sp ? env_sp : (n >= (1u << 19) ? 4u : n >= (1u << 18) ? 2u : 1u);   // measured: profiles/r02_scatter_passes.txt
     hipStream_t s = e->stream;
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
     HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
-    HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] lightly split [3] heavily split
 
-    const uint32_t rec_blocks = (uint32_t)((n + 255) / 256);
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
+    const size_t rec_words = Wire<F>::kMsmRecWords, rec_bytes = rec_words * 4;
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
     auto *digits = reinterpret_cast<uint32_t *>(e->digits.p);
     auto *counts = reinterpret_cast<uint32_t *>(e->counts.p);
@@ -1524,6 +1602,13 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *tasks = reinterpret_cast<Task *>(e->tasks.p);
     auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
+    auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
+    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
+    auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
+    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
+    uint32_t *taskbkt = two_level ? reinterpret_cast<uint32_t *>(e->taskbkt.p) : nullptr;
+    Xyzz<FpL> *bacc = two_level ? reinterpret_cast<Xyzz<FpL> *>(e->bacc.p) : nullptr;
+    PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
 
     {
         const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
@@ -1531,84 +1616,91 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");        // G2: split by component
         else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, two_lane ? "k_msm_accum2_l" : "k_msm_accum_l");
         else snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
-        lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB;
+        lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB; lp.shards = K;
         e->last_plan = lp;
     }
+    bool inline_copies = false;
+    if (staged) {
+        for (int sh = 0; sh < K; sh++)
+            if (!e->ev_copy[sh]) HIPCHK(hipEventCreateWithFlags(&e->ev_copy[sh], hipEventDisableTiming));
+        // the helper thread copies; without one (no thread to be had) this thread copies each shard itself in front of its kernels
+        inline_copies = !staged_copy.start(e->helper, e->device, e->stream2, e->ev_copy, feed, rec_bytes, const_cast<void *>(d_in), host_src);
+    }
     HIPCHK(hipEventRecord(e->ev_start, s));
-    PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
-    // Measured (profiles/r03_h2d_chunks.txt, 2^20 records, same box): 1 chunk 7.31 ms, 4 chunks 7.51, 8 chunks 7.65, 16 chunks
-    // 8.08 -- every pageable hipMemcpyAsync pays its own staging set-up and the decode + histogram it would hide are only
-    // 0.2 ms, so the default stays ONE copy followed by the kernels; EIP2537_H2D_CHUNKS=n selects the chunked form.
-    static const uint32_t env_chunks = [] { const char *v = getenv("EIP2537_H2D_CHUNKS"); return v ? (uint32_t)atoi(v) : 1u; }();
-    if (e->host_src && nslices >= 8 && env_chunks > 1) {
-        // Host input (the reference ABI): the copy is the longest single step of the call (168 MB at ~53 GB/s = 3.2 of
-        // 7.3 ms at 2^20), and decode + slice histograms need only the records that have arrived -- the histograms are
-        // per 32 768-record slice anyway.  The buffer is staged in chunks of whole slices on the engine's stream and
-        // every chunk's decode and histogram launches follow it, so they run while the host thread is busy with the
-        // next chunk's pageable copy.  The caller's buffer is not touched after the last chunk's copy has returned.
-        const uint32_t nchunks = std::min<uint32_t>(env_chunks, nslices / 2u);
-        const size_t rec_bytes = (size_t)Wire<F>::kMsmRecWords * 4;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            const uint32_t sl0 = (uint32_t)((uint64_t)nslices * c / nchunks), sl1 = (uint32_t)((uint64_t)nslices * (c + 1) / nchunks);
-            const uint32_t r0 = sl0 * kSlice, r1 = (uint32_t)std::min<size_t>((size_t)sl1 * kSlice, n);
-            HIPCHK(hipMemcpyAsync(static_cast<char *>(e->input.p) + (size_t)r0 * rec_bytes, static_cast<const char *>(e->host_src) + (size_t)r0 * rec_bytes,
-                                  (size_t)(r1 - r0) * rec_bytes, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_msm_decode<F>, dim3((r1 - r0 + 255u) / 256u), dim3(256), 0, s, in, pl, pts, ptl, digits, err, r0, r1);
-            if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(sl1 - sl0, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, sl0);
-        }
-    } else {
-        if (e->host_src) {
-            const hipError_t ce = hipMemcpyAsync(e->input.p, e->host_src, n * (size_t)Wire<F>::kMsmRecWords * 4, hipMemcpyHostToDevice, s);
+    for (int sh = 0; sh < K; sh++) {
+        const uint32_t r0 = feed.bound[sh], ns = feed.bound[sh + 1] - r0;
+        const bool last = sh == K - 1;
+        const uint32_t first_shard = sh == 0 ? 1u : 0u;
+        MsmPlan ps = pl;                                   // the shard's own plan: same windows and buckets, its own records
+        ps.n = ns;
+        const uint32_t lshift = shift_for(ns);
+        const uint32_t gshift = lshift > 6 ? lshift - 6 : 0;   // granularity of the 64 task-length classes
+        ps.L = 1u << lshift;
+        ps.max_entries = (uint64_t)ns * pl.W;
+        ps.max_tasks = (uint32_t)(pl.NB + (ps.max_entries >> lshift) + 1u);
+        const uint32_t nslices = (ns + kSlice - 1u) / kSlice, rec_blocks = (ns + 255u) / 256u;
+        const uint32_t scatter_passes = env_sp ? env_sp : (ns >= (1u << 19) ? 4u : ns >= (1u << 18) ? 2u : 1u);   // measured: profiles/r02_scatter_passes.txt
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in) + (size_t)r0 * rec_words;
+        const uint32_t split_g = last ? split_top : 0xffffffffu;          // earlier shards: one task order, one accumulate launch
+        if (staged && !inline_copies) {
+            if (!staged_copy.wait_shard(sh)) {
+                fprintf(stderr, "[eip2537_hip] host-to-device copy of shard %d failed\n", sh);
+                e->failed = true;
+                return E_MEMORY_ERROR;
+            }
+            HIPCHK(hipStreamWaitEvent(s, e->ev_copy[sh], 0));
+        } else if (host_src) {
+            // Measured (profiles/r03_h2d_chunks.txt): chunking ONE pipeline's copy with decode + histograms behind every chunk lost
+            // (7.31 -> 7.51 .. 8.08 ms at 2^20: only 0.2 ms of work could follow a chunk); that code is gone.
+            const hipError_t ce = hipMemcpyAsync(const_cast<uint32_t *>(in), static_cast<const char *>(host_src) + (size_t)r0 * rec_bytes, (size_t)ns * rec_bytes, hipMemcpyHostToDevice, s);
             if (e->copy_gate) e->copy_gate->done(e->copy_turn);            // shards of one call on one device copy in shard order (api.hip); a pageable copy returns when its last chunk is staged
             HIPCHK(ce);
         }
-        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, pl, pts, ptl, digits, err, 0u, (uint32_t)n);
-        if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
-    }
-    e->host_src = nullptr;
-    const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
-    auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260, *heavy = nullptr;
-    if (sort2) {
-        uint32_t *wtotal = blk + 2048 + 264, *wbase = wtotal + 64;
-        heavy = wbase + 64;
-        hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16, heavy);
-        hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, pl, nslices, wtotal, heavy);
-        hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
-        hipLaunchKernelGGL(k_sort_coarse_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, hist16, wbase, base, (const uint32_t *)heavy);
-        hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, pl, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
-        // the direct scatter, only when the flag is up (degenerate input)
-        hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u, (const uint32_t *)heavy);
-        hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts, (const uint32_t *)heavy);
-    } else {
-        hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
-    }
-    auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
-    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
-    HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
-    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
-    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
-    hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    if (!sort2 || heavy)
-        hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes,
-                           (const uint32_t *)heavy);
-    hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2, lenhist, gshift, split_g);
-    const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
-    hipLaunchKernelGGL(k_msm_task_perm, dim3((pl.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
-    HIPCHK(hipEventRecord(e->ev_a, s));
-    if (two_level) {
-        int st2 = launch_two_level(e, pl, n, lshift, task_blocks, red_blocks, split_g, ptl, entries, tasks, perm, totals, ranges, partial, taskoff,
-                                   split_small, split_big, winout);
-        if (st2) return st2;
-    } else {
-        // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
-        launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
-        HIPCHK(hipEventRecord(e->ev_b, s));
-        launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
-        launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
-        launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
+        HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] lightly split [3] heavily split
+        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, ps, pts, ptl, digits, err, r0);
+        if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
+        const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
+        uint32_t *heavy = nullptr;
+        if (sort2) {
+            uint32_t *wtotal = blk + 2048 + 264, *wbase = wtotal + 64;
+            heavy = wbase + 64;
+            hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, heavy);
+            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy);
+            hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
+            hipLaunchKernelGGL(k_sort_coarse_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+            hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, ps, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
+            // the direct scatter, only when the flag is up (degenerate input)
+            hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u, (const uint32_t *)heavy);
+            hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts, (const uint32_t *)heavy);
+        } else {
+            hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts);
+        }
+        HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
+        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
+        hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
+        hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
+        if (!sort2 || heavy)
+            hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes,
+                               (const uint32_t *)heavy);
+        hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
+                           split_small, split_big, totals + 2, lenhist, gshift, split_g, taskbkt, bacc, first_shard);
+        const uint32_t task_blocks = (ps.max_tasks + 255u) / 256u;
+        hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
+        hipLaunchKernelGGL(k_msm_task_perm, dim3((ps.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
+        if (last) HIPCHK(hipEventRecord(e->ev_a, s));
+        if (two_level) {
+            int st2 = E_SUCCESS;
+            st2 = launch_two_level_or_shard(e, ps, ns, lshift, task_blocks, red_blocks, split_g, last, ptl, entries, tasks, perm, totals, ranges, partial, taskoff,
+                                            split_small, split_big, taskbkt, bacc, reinterpret_cast<Xyzz<FpL> *>(e->rcsum.p), winout, first_shard);
+            if (st2) return st2;
+        } else {
+            // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
+            launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
+            HIPCHK(hipEventRecord(e->ev_b, s));
+            launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
+            launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
+            launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
+        }
     }
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
@@ -1620,10 +1712,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipMemcpyAsync(hw.data(), winout + (dev_winsum ? red_blocks : 0u), nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     drain.armed = false;
+    staged_copy.finish();                       // (the helper has long finished: every copy event was waited for above)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
-    if (hipEventElapsedTime(&ms, e->ev_start, e->ev_a) == hipSuccess) e->last_aux_ms[0] = ms;     // decode .. task order
+    if (hipEventElapsedTime(&ms, e->ev_start, e->ev_a) == hipSuccess) e->last_aux_ms[0] = ms;     // decode .. task order (staged call: everything before the last shard's accumulate)
     if (hipEventElapsedTime(&ms, e->ev_b, e->ev_stop) == hipSuccess) e->last_aux_ms[1] = ms;      // fold + bucket reduce
     if (herr != ~0ull) return (int)(herr & 7ull);
 

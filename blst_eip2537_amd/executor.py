@@ -135,6 +135,8 @@ def lib():
     L.eip2537_hip_last_plan.restype = ctypes.c_int
     L.eip2537_hip_last_plan.argtypes = [ctypes.c_char_p, ctypes.c_size_t] + [ctypes.POINTER(ctypes.c_int)] * 3 + \
                                        [ctypes.POINTER(ctypes.c_uint32)] * 2
+    L.eip2537_hip_last_shards.restype = ctypes.c_int
+    L.eip2537_hip_last_shards.argtypes = []
     L.eip2537_hip_last_timing_aux.restype = None
     L.eip2537_hip_last_timing_aux.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.eip2537_hip_last_timing.restype = None
@@ -266,7 +268,7 @@ class Eip2537Executor:
                                        ctypes.byref(u), ctypes.byref(b)) != 0:
             return None
         return {"kernel": name.value.decode(), "window_bits": c.value, "windows": w.value, "lanes": ln.value,
-                "units": u.value, "buckets": b.value}
+                "units": u.value, "buckets": b.value, "shards": int(lib().eip2537_hip_last_shards())}
 
     @staticmethod
     def device_count():

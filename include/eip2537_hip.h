@@ -70,6 +70,9 @@ void eip2537_hip_last_timing_aux(float *aux1_ms, float *aux2_ms);
  * when no GPU call has been made yet. */
 int eip2537_hip_last_plan(char *kernel_name, size_t cap, int *window_bits, int *windows, int *lanes,
                           uint32_t *units, uint32_t *buckets);
+/* Record shards that call was staged in: a large host-input bls12_g1multiexp is copied shard by shard, each shard decoded,
+ * sorted and accumulated behind its own copy into ONE bucket space (1: one copy, or input already in HBM; 0: no call yet). */
+int eip2537_hip_last_shards(void);
 /* Engine slots keep the workspace of the largest call they served (about 0.9 GB after one
  * 2^20-record MSM; a slot above $EIP2537_HIP_KEEP_MB, default 4096, frees it when the call ends).
  * This releases the workspace of every idle slot holding more than keep_bytes; returns the bytes freed. */

@@ -62,20 +62,33 @@ if mode == "small":                      # EIP2537_HIP_SPLIT_MIN=64: every call 
     e[20 * 384 + 128:20 * 384 + 384] = m.encode_g2((((1, 0)), ((1, 0))))         # off-curve G2, shard 0 -> wins
     assert call(X.pairing, bytes(e)) == (1, None)
     assert X.last_plan() is not None
-elif mode == "pipe":                     # ONE device, EIP2537_H2D_PIPELINE=3: every host-input call of >= 2^16 records runs as 3 shards
-    n = (1 << 16) + 1                    # whose copies follow each other on the same device (api.hip, pipeline_shards / CopyGate)
-    g1 = clib.gen_msm_input("g1", n, A, B, 4242)
+elif mode == "pipe":                     # ONE device.  G1 (round 4): EIP2537_H2D_STAGES=1,2,2 stages every c = 16 call as three record shards
+    n = (1 << 17) + 1                    # into ONE bucket space (msm.hip: StagedCopy, bucket accumulators); G2: EIP2537_H2D_PIPELINE=3, three
+    g1 = clib.gen_msm_input("g1", n, A, B, 4242)       # independent shard pipelines whose copies follow each other (CopyGate)
     assert call(X.g1_multiexp, g1) == clib.call("bls12_g1multiexp", g1)
-    assert X.last_plan()["units"] in (n // 3, n // 3 + 1), X.last_plan()
-    bad = bytearray(g1); bad[60000 * 160 + 0] = 1                      # pad byte: INVALID_ELEMENT in shard 2
+    assert X.last_plan()["units"] == n and X.last_plan()["shards"] == 3, X.last_plan()
+    bad = bytearray(g1); bad[120000 * 160 + 0] = 1                     # pad byte: INVALID_ELEMENT in shard 2
     assert call(X.g1_multiexp, bytes(bad)) == (3, None)
     bad[10 * 160 + 16:10 * 160 + 128] = m.encode_g1((1, 1))[16:]       # (1,1) off curve in shard 0 -> wins
     assert call(X.g1_multiexp, bytes(bad)) == (1, None)
+    # buckets shared between shards: the same point with the same scalar in every shard (doubling inside a bucket accumulator),
+    # a shard that cancels an earlier one (accumulators fall back to infinity), a shard of infinities
+    P = m.g1_mul(m.G1, 0xabcdef)
+    rec = lambda pt, k: m.encode_g1(pt) + m.encode_scalar(k)
+    third = n // 5 + 7
+    body = bytearray(g1)
+    for i in range(3): body[(i * 52429 + 5) * 160:(i * 52429 + 6) * 160] = rec(P, 0x1234567)
+    assert call(X.g1_multiexp, bytes(body)) == clib.call("bls12_g1multiexp", bytes(body))
+    canc = bytearray(g1[:third * 160]) + bytearray(len(g1) - third * 160)
+    for i in range(third, n):                                           # records third.. : infinity, except a mirror of shard 0's first records
+        j = i - third
+        if j < third: canc[i * 160:i * 160 + 160] = g1[j * 160:j * 160 + 64] + m.encode_g1(m.ec_neg(m.FP, m.decode_g1(g1[j * 160:j * 160 + 128])))[64:] + g1[j * 160 + 128:j * 160 + 160]
+    assert call(X.g1_multiexp, bytes(canc)) == (0, bytes(128))
     gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
     g2 = X.gen_msm_input("g2", 1 << 16, A, B, 0x25370100 + 16)
     assert call(X.g2_multiexp, g2) == (0, gold("g2msm_2p16.hex"))
-    # concurrent pipelined calls: shards take their engine slot only when it is their turn to copy, so 6 callers x 3 shards
-    # on 8 slots cannot starve each other
+    assert X.last_plan()["units"] in ((1 << 16) // 3, (1 << 16) // 3 + 1), X.last_plan()
+    # concurrent staged calls: each holds one engine slot and its helper thread
     import threading
     want = clib.call("bls12_g1multiexp", g1)
     res = [None] * 6
@@ -83,20 +96,20 @@ elif mode == "pipe":                     # ONE device, EIP2537_H2D_PIPELINE=3: e
     th = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
     [t.start() for t in th]; [t.join() for t in th]
     assert all(r == want for r in res)
-elif mode == "pipe_default":             # ONE device, default policy: 2^20 G1 records = 3 shards, 2^16 = one pipeline
+elif mode == "pipe_default":             # ONE device, default policy: 2^20 G1 records staged in several shards, 2^16 = one copy
     gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
     g1 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
     assert call(X.g1_multiexp, g1) == (0, gold("g1msm_2p20.hex"))
-    assert X.last_plan()["units"] in (349525, 349526), X.last_plan()
+    assert X.last_plan()["units"] == 1 << 20 and X.last_plan()["shards"] >= 3, X.last_plan()
     g1s = X.gen_msm_input("g1", 1 << 16, A, B, 0x25370000 + 16)
     assert call(X.g1_multiexp, g1s) == (0, gold("g1msm_2p16.hex"))
-    assert X.last_plan()["units"] == 1 << 16
+    assert X.last_plan()["units"] == 1 << 16 and X.last_plan()["shards"] == 1
 else:                                    # default thresholds at the BASELINE sizes
     gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
     g1 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
     assert call(X.g1_multiexp, g1) == (0, gold("g1msm_2p20.hex"))
     p, _ = X.last_timing()
-    assert X.last_plan()["units"] == 1 << 18, X.last_plan()            # each device got half the records, in two pipelined shards
+    assert X.last_plan()["units"] == 1 << 19 and X.last_plan()["shards"] >= 2, X.last_plan()     # each device got half the records, staged in shards
     g2 = X.gen_msm_input("g2", 1 << 16, A, B, 0x25370100 + 16)
     assert call(X.g2_multiexp, g2) == (0, gold("g2msm_2p16.hex"))
     assert X.last_plan()["units"] == 1 << 15, X.last_plan()
@@ -131,7 +144,7 @@ def test_split_baseline_sizes_default_thresholds(tmp_path, clib, X):
 
 
 def test_pipelined_host_input_three_shards_one_device(tmp_path, clib, X):
-    _run(tmp_path, "pipe", "0", {"EIP2537_H2D_PIPELINE": "3"})
+    _run(tmp_path, "pipe", "0", {"EIP2537_H2D_PIPELINE": "3", "EIP2537_H2D_STAGES": "1,2,2"})
 
 
 def test_pipelined_host_input_default_policy(tmp_path, clib, X):

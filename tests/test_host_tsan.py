@@ -36,3 +36,11 @@ def test_host_concurrency_under_thread_sanitizer(tmp_path):
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert " 0 mismatches" in r.stdout, r.stdout
+    # staged G1 calls (round 4: StagedCopy / Helper of csrc/engine.h -- the slot's helper thread copies the record shards while the
+    # calling thread consumes them), on one stub device and nested inside the split over two
+    for ndev in ("1", "2"):
+        env.update(EIP_STUB_NDEV=ndev, EIP2537_H2D_PIPELINE="1", EIP2537_H2D_STAGES="1,3,3,2")
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert " 0 mismatches" in r.stdout, r.stdout

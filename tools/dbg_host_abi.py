@@ -13,10 +13,13 @@ n = 1 << log2n
 inp = X.gen_msm_input(grp, n, A, B, (0x25370000 if grp == "g1" else 0x25370100) + log2n)
 gp = os.path.join(ROOT, "tests", "golden", "%smsm_2p%d.hex" % (grp, log2n))
 gold = bytes.fromhex(open(gp).read().strip()) if os.path.exists(gp) else None
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 23
 ts = []
-for i in range(10):
+for i in range(reps):
     t0 = time.perf_counter()
     out = X.g1_multiexp(inp) if grp == "g1" else X.g2_multiexp(inp)
     ts.append((time.perf_counter() - t0) * 1e3)
-print(grp, "H2D_PIPELINE=%s H2D_CHUNKS=%s n=2^%d golden_ok=%s host-ABI ms min %.3f med %.3f" % (os.environ.get("EIP2537_H2D_PIPELINE", "default"), os.environ.get("EIP2537_H2D_CHUNKS", "default"), log2n,
-      None if gold is None else out == gold, min(ts[2:]), sorted(ts[2:])[len(ts[2:]) // 2]), flush=True)
+w = ts[3:]
+print(grp, "H2D_PIPELINE=%s H2D_STAGES=%s n=2^%d shards=%s golden_ok=%s host-ABI ms min %.3f med %.3f mean %.3f (n=%d)" % (
+      os.environ.get("EIP2537_H2D_PIPELINE", "default"), os.environ.get("EIP2537_H2D_STAGES", "default"), log2n, (X.last_plan() or {}).get("shards"),
+      None if gold is None else out == gold, min(w), sorted(w)[len(w) // 2], sum(w) / len(w), len(w)), flush=True)

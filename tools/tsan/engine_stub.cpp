@@ -15,7 +15,25 @@ MsmPlan msm_make_plan(uint32_t n, int, bool) { MsmPlan p{}; p.n = n; p.c = 8; p.
 
 // value of a record: [k mod 2^8] P  (one window of the scalar: enough for a sum that depends on every record)
 template <class F> static int msm_stub(Engine *e, const void *d_in, size_t n, Xyzz<F> *acc_out, Xyzz<F> *wins) {
-    if (e->host_src) {                                        // host input: the real pipeline stages it itself (msm.hip)
+    const ShardFeed feed = e->feed;
+    e->feed.k = 0;
+    StagedCopy staged;                                        // as in msm.hip: declared before anything that can return
+    if (e->host_src && feed.k > 1 && sizeof(F) == sizeof(Fp)) {
+        // staged call (msm.hip): the slot's helper thread copies the shards, this thread waits for each shard's hand-over
+        // before it "launches" (here: reads) that shard
+        for (int sh = 0; sh < feed.k; sh++)
+            if (!e->ev_copy[sh] && hipEventCreateWithFlags(&e->ev_copy[sh], hipEventDisableTiming) != hipSuccess) return E_MEMORY_ERROR;
+        const void *src = e->host_src;
+        e->host_src = nullptr;
+        const bool threaded = staged.start(e->helper, e->device, e->stream2, e->ev_copy, feed, Wire<F>::kMsmRecWords * 4, e->input.p, src);
+        for (int sh = 0; sh < feed.k; sh++) {
+            if (threaded) { if (!staged.wait_shard(sh)) return E_MEMORY_ERROR; }
+            else memcpy(static_cast<char *>(e->input.p) + (size_t)feed.bound[sh] * Wire<F>::kMsmRecWords * 4,
+                        static_cast<const char *>(src) + (size_t)feed.bound[sh] * Wire<F>::kMsmRecWords * 4,
+                        (size_t)(feed.bound[sh + 1] - feed.bound[sh]) * Wire<F>::kMsmRecWords * 4);
+        }
+        staged.finish();
+    } else if (e->host_src) {                                 // host input: the real pipeline stages it itself (msm.hip)
         memcpy(e->input.p, e->host_src, n * Wire<F>::kMsmRecWords * 4);
         if (e->copy_gate) e->copy_gate->done(e->copy_turn);  // a shard of a pipelined call: the next shard may copy (msm.hip)
         e->host_src = nullptr;

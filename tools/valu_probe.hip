@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #define ITERS 4096
 #define CHAINS 8
@@ -57,9 +58,37 @@ template <int KIND> static void run(const char *name, uint32_t *d_out, double op
     printf("%-28s %8.1f G lane-ops/s  (%.3f ms)\n", name, lane_ops / (ms * 1e-3) / 1e9, ms / 5);
 }
 
-int main() {
+// Sustained form (round 4): back-to-back v_mad_u64_u32 launches for `seconds`, the rate printed per ~0.25 s window -- the burst
+// figure above is a 0.6 ms probe, and the part lowers its clock under sustained VALU load.
+static void sustained(uint32_t *d_out, double seconds) {
+    const int blocks = 256 * 8, per = 64;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    double elapsed = 0, first = 0, last = 0, sum = 0;
+    int windows = 0;
+    while (elapsed < seconds) {
+        hipEventRecord(e0);
+        for (int r = 0; r < per; r++) probe<0><<<blocks, 256>>>(d_out, 777u + r);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double rate = (double)per * blocks * 256.0 * ITERS * CHAINS / (ms * 1e-3) / 1e9;
+        printf("  t = %6.3f s   %8.1f G lane-ops/s\n", elapsed, rate);
+        if (!windows) first = rate;
+        last = rate;
+        sum += rate;
+        windows++;
+        elapsed += ms * 1e-3;
+    }
+    printf("v_mad_u64_u32 sustained %.2f s: first window %.1f, last %.1f, mean %.1f G lane-ops/s\n", elapsed, first, last, sum / windows);
+}
+
+int main(int argc, char **argv) {
     uint32_t *d_out;
     hipMalloc(&d_out, 256 * 8 * 256 * 4);
+    if (argc > 1) { sustained(d_out, atof(argv[1])); return 0; }
     run<0>("v_mad_u64_u32", d_out, 1);
     run<1>("v_mul_lo_u32(+add)", d_out, 1);
     run<2>("v_mul_hi_u32(+add)", d_out, 1);
