@@ -1117,6 +1117,17 @@ API int eip2537_hip_init(int device) {
     if (!ok) g_device_request = -1;
     return ok ? 0 : E_MEMORY_ERROR;
 }
+// Start-up hook for embedders (and the static shim, which exports the same name): ONCE from main(), before the process starts
+// threads and before its first HIP call -- the only place where the environment can be touched safely.  Never overrides the
+// embedder's own value.  eip2537_hip_hw_queues() reports what the runtime will see / has seen.
+API int eip2537_hip_early_init(void) {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    return 0;
+}
+API int eip2537_hip_hw_queues(void) {
+    const char *v = getenv("GPU_MAX_HW_QUEUES");
+    return v && atoi(v) > 0 ? atoi(v) : 4;
+}
 API int eip2537_hip_device_count(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     return device_select_locked() ? g_nsplit : 0;

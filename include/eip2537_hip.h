@@ -70,6 +70,13 @@ void eip2537_hip_last_timing_aux(float *aux1_ms, float *aux2_ms);
  * when no GPU call has been made yet. */
 int eip2537_hip_last_plan(char *kernel_name, size_t cap, int *window_bits, int *windows, int *lanes,
                           uint32_t *units, uint32_t *buckets);
+/* Start-up hook, optional: call ONCE from main(), before the process starts threads and before its first HIP call.  Sets
+ * GPU_MAX_HW_QUEUES=16 unless the embedder has set it (the HIP runtime reads it when it initialises; with the default of 4,
+ * concurrent callers' streams share 4 hardware queues).  The library never touches the environment from inside a precompile
+ * call.  The static shim (shim/libblst_eip2537.a) exports the same name and also loads the engine.  Returns 0.
+ * eip2537_hip_hw_queues(): the value the HIP runtime sees (4 when unset), so that an embedder can assert it. */
+int eip2537_hip_early_init(void);
+int eip2537_hip_hw_queues(void);
 /* Record shards that call was staged in: a large host-input bls12_g1multiexp is copied shard by shard, each shard decoded,
  * sorted and accumulated behind its own copy into ONE bucket space (1: one copy, or input already in HBM; 0: no call yet). */
 int eip2537_hip_last_shards(void);

@@ -40,6 +40,15 @@ static void *shim_handle(void) {
     return h;
 }
 
+/* Optional start-up hook (include/eip2537_hip.h): call it ONCE from main(), before the process starts threads and before its
+ * first HIP call.  The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises (default 4: concurrent callers would share 4
+ * hardware queues); a lazy dlopen from a caller thread cannot set it safely (setenv races with getenv elsewhere), this can.
+ * The embedder's own value is never overridden.  Also loads the engine, so that the first precompile call does not pay for it. */
+int eip2537_hip_early_init(void) {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    return shim_handle() ? 0 : SHIM_MEMORY_ERROR;
+}
+
 static int shim_forward(precompile_fn *slot, const char *name, byte *out, const byte *in, size_t len) {
     precompile_fn f = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
     if (!f) {
