@@ -48,7 +48,9 @@ A = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6
 B = 0x0123456789abcdef0fedcba987654321
 R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MAD_PEAK = 29441.6e9           # v_mad_u64_u32 lane-ops/s, chip-wide, measured (profiles/r01_valu_probe.txt)
+MAD_PEAK = 33775e9             # v_mad_u64_u32 lane-ops/s, chip-wide, SUSTAINED (tools/valu_probe.hip 2.0: 33.8 T from the second 34-ms window on,
+                               # profiles/r04_valu_probe.txt).  Rounds 1-3 priced against 29.44 T, the probe's first 3-ms burst, taken before the
+                               # clock has ramped up: every VALU fraction of this round is therefore ~13 % LOWER than the same kernel's in round 3
 MADS_PER_FP_PRODUCT = 338      # 13 x 13 product + 13 x 13 reduction columns of 30-bit limbs (csrc/field.h)
 REC = {"g1msm": 160, "g2msm": 288, "pairing": 384}          # algorithmic bytes per unit
 FULL = {"g1msm": "eip2537_hip_g1multiexp_dev", "g2msm": "eip2537_hip_g2multiexp_dev",
@@ -113,7 +115,7 @@ def pairing_valu(k, walk_ms, check_ms, fold_ms, pipeline_ms):
             "device_pipeline": {"lane_mads": total, "ms": pipeline_ms, "frac": total / (pipeline_ms * 1e-3) / MAD_PEAK if pipeline_ms > 0 else None},
             "note": "executed multiply-adds per pair x pairs / kernel time from HIP events on the engine's streams (membership runs on a second "
                     "stream beside the walk; k_pair_fold's interval includes k_pair_tree2); peak = chip-wide v_mad_u64_u32 rate measured by "
-                    "tools/valu_probe.hip (profiles/r01_valu_probe.txt)"}
+                    "tools/valu_probe.hip, sustained form (profiles/r04_valu_probe.txt)"}
 
 
 def traffic_for(wl, log2n, kernel):
@@ -446,7 +448,7 @@ def main():
                 "achieved": mads / (k_ms * 1e-3) / 1e12, "peak": MAD_PEAK / 1e12, "unit": "T mad lane-ops/s",
                 "frac": mads / (k_ms * 1e-3) / MAD_PEAK, "fp_products_per_launch": prods,
                 "note": "algorithmic Fp products = records x windows (%d, c = %d) x 10 (x3 over Fp2), %d multiply-adds each; "
-                        "peak = chip-wide v_mad_u64_u32 rate measured by tools/valu_probe.hip (profiles/r01_valu_probe.txt)"
+                        "peak = chip-wide v_mad_u64_u32 rate measured by tools/valu_probe.hip, sustained form (profiles/r04_valu_probe.txt)"
                         % (plan["windows"], plan.get("window_bits", 0), MADS_PER_FP_PRODUCT)}
             # multiply-adds the G1 kernels really execute per mixed addition: the two squarings take 260 of them
             # (91 + 169), and the limb-form kernel reduces R (Q - x3) - y1 PPP once (338 + 169)

@@ -1294,8 +1294,11 @@ k_msm_reduce1(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
 // kernels see W + 1 "virtual windows" of B buckets each; the upper half TB of the top window (virtual window W) only adds
 // 128 to its row weights.  16 virtual windows are exactly 1 024 waves of 16-bucket chains -- one per SIMD --, and TB's sums
 // (k_msm_rowcol on a second stream) hide behind the accumulate of the other windows: TB's tasks are accumulated first.
-static constexpr uint32_t kRcCols = 256, kRcChain = 16;
+static constexpr uint32_t kRcCols = 256;
 static constexpr uint32_t kRcRows = 128, kRcPerWindow = kRcRows + kRcCols;                 // B = 32 768 = 128 x 256
+// CH: buckets per lane chain -- 16 on a whole MI355X (16 virtual windows = 1 024 waves = one per SIMD), 32 / 64 on a device that reports
+// fewer SIMDs (chip_shape), so that the launch on the critical path still places one wave per SIMD
+template <uint32_t kRcChain>
 __global__ void __launch_bounds__(256)
 k_msm_rowcol(const Xyzz<FpL> *__restrict__ bacc, uint32_t B, uint32_t w0, Xyzz<FpL> *__restrict__ rc) {
     // round 4: the buckets' sums are read from the bucket accumulators bacc[bucket] (k_msm_accum_l / k_msm_fold_*) -- no task-offset
@@ -1417,7 +1420,15 @@ static int launch_two_level(Engine *e, const MsmPlan &pl, size_t ns, uint32_t ls
                             const TwoLevelArgs &a) {
     hipStream_t s = e->stream;
     const uint32_t tb_blocks = (pl.B + (uint32_t)(ns >> lshift) + 1u + 255u) / 256u;     // at most B buckets + ns / L full tasks
-    const uint32_t unit_blocks = (2u * pl.B / kRcChain) / 256u;                          // blocks of one virtual window in k_msm_rowcol
+    // chain length: the shortest whose W virtual windows place at most one wave per SIMD (16 on 1 024 SIMDs)
+    const uint32_t simds = chip_shape(e->device).simds;
+    const uint32_t chain = (uint32_t)pl.W * (2u * pl.B / 16u / 64u) <= simds ? 16u : (uint32_t)pl.W * (2u * pl.B / 32u / 64u) <= simds ? 32u : 64u;
+    const uint32_t unit_blocks = (2u * pl.B / chain) / 256u;                             // blocks of one virtual window in k_msm_rowcol
+    auto rowcol = [&](hipStream_t st, uint32_t blocks, uint32_t w0) {
+        if (chain == 16u) hipLaunchKernelGGL(k_msm_rowcol<16u>, dim3(blocks), dim3(256), 0, st, (const Xyzz<FpL> *)a.bacc, pl.B, w0, a.rc);
+        else if (chain == 32u) hipLaunchKernelGGL(k_msm_rowcol<32u>, dim3(blocks), dim3(256), 0, st, (const Xyzz<FpL> *)a.bacc, pl.B, w0, a.rc);
+        else hipLaunchKernelGGL(k_msm_rowcol<64u>, dim3(blocks), dim3(256), 0, st, (const Xyzz<FpL> *)a.bacc, pl.B, w0, a.rc);
+    };
     // stream3, beside the main accumulate (a launch of TB's ~770 waves alone would be a latency chain on an empty chip: 0.25 ms lost)
     hipStream_t s3 = e->stream3;
     HIPCHK(hipEventRecord(e->ev_j3, s));
@@ -1425,13 +1436,13 @@ static int launch_two_level(Engine *e, const MsmPlan &pl, size_t ns, uint32_t ls
     hipLaunchKernelGGL(k_msm_accum_l, dim3(tb_blocks), dim3(256), 0, s3, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, a.ranges + 2, a.taskbkt, a.bacc, a.first_shard);
     hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s3, a.partial, a.taskoff, a.split_small, a.totals + 2, split_g, 0xffffffffu, a.bacc);
     hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s3, a.partial, a.taskoff, a.split_big, a.totals + 2, split_g, 0xffffffffu, a.bacc);
-    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks), dim3(256), 0, s3, (const Xyzz<FpL> *)a.bacc, pl.B, (uint32_t)pl.W, a.rc);
+    rowcol(s3, unit_blocks, (uint32_t)pl.W);
     HIPCHK(hipEventRecord(e->ev_j2, s3));
     hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, a.ranges, a.taskbkt, a.bacc, a.first_shard);
     HIPCHK(hipEventRecord(e->ev_b, s));
     hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, a.partial, a.taskoff, a.split_small, a.totals + 2, 0u, split_g, a.bacc);
     hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, a.partial, a.taskoff, a.split_big, a.totals + 2, 0u, split_g, a.bacc);
-    hipLaunchKernelGGL(k_msm_rowcol, dim3(unit_blocks * (uint32_t)pl.W), dim3(256), 0, s, (const Xyzz<FpL> *)a.bacc, pl.B, 0u, a.rc);      // 16 units: 1 024 waves
+    rowcol(s, unit_blocks * (uint32_t)pl.W, 0u);                                         // 16 units: 1 024 waves
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     hipLaunchKernelGGL(k_msm_reduce_rc, dim3(red_blocks), dim3(256), 0, s, (const Xyzz<FpL> *)a.rc, pl.W, a.winout);
     return E_SUCCESS;
@@ -1964,7 +1975,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
         if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");
         else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2_l");
         else snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2<%s>", ReduceCfg<F>::kName);
-        lp.c = pl.c; lp.windows = pl.W; lp.lanes = 2; lp.units = (uint32_t)n; lp.buckets = pl.NB;
+        lp.c = pl.c; lp.windows = pl.W; lp.lanes = 2; lp.units = (uint32_t)n; lp.buckets = pl.NB; lp.shards = 1;
         e->last_plan = lp;
     }
     HIPCHK(hipEventRecord(e->ev_start, s));

@@ -456,11 +456,11 @@ static int pairing_reserve(Engine *e, size_t k, size_t err_bytes, size_t winout_
 }
 static int pairing_front(Engine *e, const uint32_t *in, size_t k, const uint32_t *d_coff, int M, const PairBufs &b) {
     const uint32_t line_blocks = (uint32_t)((k + 7) / 8), check_blocks = (uint32_t)((k + 15) / 16);
-    const bool excl = line_blocks + check_blocks <= 1024u;       // one wave per SIMD while everything fits the chip
+    const bool excl = line_blocks + check_blocks <= chip_shape(e->device).simds;       // one wave per SIMD while everything fits the chip (1 024 SIMDs on a whole MI355X)
     {
         LastPlan lp{};
         snprintf(lp.kernel, sizeof lp.kernel, "%s", excl ? "k_pair_lines8<true>" : "k_pair_lines8<false>");
-        lp.windows = kSteps; lp.lanes = 8; lp.units = (uint32_t)k;
+        lp.windows = kSteps; lp.lanes = 8; lp.units = (uint32_t)k; lp.shards = 1;
         e->last_plan = lp;
     }
     const CallMap cm{d_coff, M};
@@ -491,7 +491,10 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     }
     // blocks per step: as many as keep the whole grid (blocks x 68 steps) in ONE round of 2 blocks per CU (512
     // slots); one block more than that and the kernel takes two block-times
-    const uint32_t max_blocks_per_step = (256u * EIP_FOLD_WAVES) / kSteps;     // 7
+    //  k_pair_tree2 stacks the per-block elements of a step at a pitch of kGroupPitch inside kTreeQuads slots
+    static_assert((256 * EIP_FOLD_WAVES) / kSteps <= kGroupPitch, "k_pair_tree2: blocks per step exceed the group pitch");
+    static_assert(kGroupSteps * kGroupPitch <= kTreeQuads, "k_pair_tree2: a group's elements exceed the block's slots");
+    const uint32_t max_blocks_per_step = std::max(1u, std::min<uint32_t>((uint32_t)kGroupPitch, (chip_shape(e->device).cus * EIP_FOLD_WAVES) / kSteps));     // 7 on 256 CUs
     const uint32_t tree_blocks = (uint32_t)std::min<size_t>(max_blocks_per_step, (k + kTreeQuads - 1) / kTreeQuads);
     PairBufs b{};
     int st = pairing_reserve(e, k, 64, (size_t)kSteps * tree_blocks * kElemWords * 4 + (size_t)kSteps * sizeof(Fp12), b);

@@ -92,16 +92,25 @@ def test_bench_gpus_flag_is_not_ignored():
     assert cp.returncode == 2 and "refusing" in cp.stderr and "n_gpus" not in cp.stdout
 
 
-def test_two_rank_gloo_shard_gather_combine(tmp_path, clib, X):
+def _gloo_ranks(tmp_path, world, port):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
     procs = []
-    for r in range(2):
+    for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "ok" in o
+
+
+def test_two_rank_gloo_shard_gather_combine(tmp_path, clib, X):
+    _gloo_ranks(tmp_path, 2, 29611)
+
+
+def test_eight_rank_gloo_shard_gather_combine(tmp_path, clib, X):
+    """BASELINE configs[4] is 8 GPUs: the same exchange with eight ranks (75-record shards, one pair per rank)."""
+    _gloo_ranks(tmp_path, 8, 29612)
