@@ -44,6 +44,7 @@ hipError_t DevBuf::reserve(size_t bytes) {
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; return e; }
     cap = want;
+    fresh = true;
     return hipSuccess;
 }
 void DevBuf::release() {
@@ -183,22 +184,12 @@ static bool device_select_locked() {
     g_nsplit = ns_out;
     return g_nsplit > 0;
 }
-// stream3 carries the small side chain of the two-level bucket reduce (msm.hip) that must get its waves placed WHILE the main
-// stream's accumulate still has blocks to dispatch: highest priority the device offers
-static bool create_priority_stream(hipStream_t *s) {
-    int lo = 0, hi = 0;                              // numerically lowest = highest priority
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
-    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess) return true;
-    (void)hipGetLastError();
-    return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
-}
 static bool slot_init(Engine &e, int ordinal) {
     if (e.ready) return true;
     warn_hw_queues_once();
     e.device = ordinal;
+    // (stream2 / stream3 are created by the first pipeline that needs them: Engine::need_stream2 / need_stream3)
     bool ok = hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking) == hipSuccess &&
-              create_priority_stream(&e.stream3) &&
               hipEventCreate(&e.ev_start) == hipSuccess && hipEventCreate(&e.ev_stop) == hipSuccess &&
               hipEventCreate(&e.ev_a) == hipSuccess && hipEventCreate(&e.ev_b) == hipSuccess &&
               hipEventCreate(&e.ev_j2) == hipSuccess && hipEventCreate(&e.ev_j3) == hipSuccess && hipEventCreate(&e.ev_c) == hipSuccess;

@@ -14,6 +14,7 @@ namespace eip {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool fresh = false;    // set by reserve() when it allocated: the contents are undefined (a consumer that keeps state in the buffer re-initialises it and clears the flag)
     hipError_t reserve(size_t bytes);
     void release();
 };
@@ -203,6 +204,24 @@ struct Engine {
     float last_aux_ms[2] = {0.f, 0.f};   // pairing: G1 membership kernel, line products (fold + tree2); MSM: sort stage (decode .. task order), fold + reduce
     LastPlan last_plan{};
 
+    // stream2 (a pairing batch's G1 membership kernel, the copies of a staged call) and stream3 (the side chain of the two-level
+    // bucket reduce: highest priority the device offers, so that its waves are placed WHILE the main stream's accumulate still has
+    // blocks to dispatch) are created by the first pipeline that needs them.  Round 4: a slot that only ever serves small calls
+    // keeps ONE stream -- with three per slot, one of them a priority stream, 64 native callers of 128-record multiexps ran at
+    // 1.1-1.2e4 calls/s against 2.0-2.5e4 before the priority streams existed (profiles/r04_concurrent_callers_native.txt).
+    hipError_t need_stream2() {
+        if (stream2) return hipSuccess;
+        return hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking);
+    }
+    hipError_t need_stream3() {
+        if (stream3) return hipSuccess;
+        int lo = 0, hi = 0;                              // numerically lowest = highest priority
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+        if (hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking);
+    }
+
     template <class Fn> void for_each_buf(Fn &&fn) {
         for (DevBuf *b : {&input, &misc, &pts, &digits, &hist16, &slice_base, &counts, &offsets, &taskoff, &scan_blk,
                           &entries, &tasks, &perm, &split_lists, &partial, &winout, &bacc, &taskbkt, &rcsum}) fn(*b);
@@ -230,6 +249,7 @@ struct MsmPlan {
     uint32_t NB;       // total buckets
     uint32_t L;        // max entries per accumulate task
     uint32_t S;        // buckets per reduce segment
+    uint32_t slice;    // records per block of the counting-sort kernels (msm.hip: msm_slice_for)
     uint32_t max_tasks;
     uint64_t max_entries;
 };

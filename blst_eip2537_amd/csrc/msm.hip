@@ -42,6 +42,17 @@ namespace eip {
     } while (0)
 
 struct Task { uint32_t start, len; };
+static constexpr uint32_t kSlice = 32768;             // largest slice of the counting-sort kernels (records per block)
+static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit counters
+// Records per (slice, window) block of the counting-sort kernels.  Round 3 used 32 768 everywhere: a 2^16-record call then ran its
+// scatter on 40 blocks (66 of its 143 us of sort stage) and a 245 760-record shard of a staged call its coarse scatter on 128 blocks
+// of one per CU (45 us; the whole 2^20: 102 us in two rounds).  Now: the power of two that gives the windows ~512 blocks in all.
+static uint32_t msm_slice_for(uint32_t n, int W, bool sort2) {
+    uint32_t want = (uint32_t)(((uint64_t)n * (uint64_t)W + 511u) / 512u), s = sort2 ? 4096u : 2048u;
+    const uint32_t cap = sort2 ? 16384u : kSlice;
+    while (s < want && s < cap) s <<= 1;
+    return s;
+}
 
 ChipShape chip_shape(int device) {
     static std::mutex mu;
@@ -106,6 +117,7 @@ MsmPlan msm_make_plan(uint32_t n, int c_override, bool g2) {
     // back to the planner's own choice rather than returning an empty plan
     if (best_cost == 1e300 && c_override) return msm_make_plan(n, -1, g2);
     MsmPlan &pl = best;
+    pl.slice = kSlice;                           // refined in msm_device_t (msm_slice_for)
     pl.L = 64;                                   // refined in msm_device_t
     pl.S = 16;                                   // refined per field in msm_device_t
     pl.max_entries = (uint64_t)n * pl.W;
@@ -236,9 +248,8 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
     });
 }
 
-// Three-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
-//   k_msm_scan_sums  [1024 buckets per block]  block totals of (entries, tasks)
-//   k_msm_scan_top   [1 block]                 exclusive scan of the block totals
+// Two-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
+//   k_msm_scan_sums  [1024 buckets per block]  block totals of (entries, tasks); its last block scans the block totals
 //   k_msm_scan_apply [1024 buckets per block]  local scan + block base -> offsets, taskoff
 __device__ __forceinline__ void block_scan_1024(uint32_t &e, uint32_t &k, uint32_t *se, uint32_t *st) {
     // inclusive Hillis-Steele scan of (e, k) over the 1024 threads of the block
@@ -256,8 +267,24 @@ __device__ __forceinline__ void block_scan_1024(uint32_t &e, uint32_t &k, uint32
     e = se[t];
     k = st[t];
 }
+// (round 4: k_msm_scan_top was a launch of its own; the LAST block of k_msm_scan_sums to finish -- ticket counter at blk[2 * 1024] --
+// now runs it, and also clears the task-length histograms that k_msm_tasks fills next: two launches and one memset less per shard)
+__device__ __forceinline__ bool last_block_done(uint32_t *counter, uint32_t nblocks) {
+    __shared__ uint32_t s_ticket;
+    __threadfence();                                             // this block's results are visible before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(counter, 1u);
+    __syncthreads();
+    const bool last = s_ticket == nblocks - 1u;
+    if (last) {
+        __threadfence();
+        if (threadIdx.x == 0) *counter = 0u;                     // ready for the next launch
+    }
+    return last;
+}
 __global__ void __launch_bounds__(1024)
-k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, uint32_t *__restrict__ blk) {
+k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, uint32_t *blk, uint32_t *ticket,
+                uint32_t *taskoff, uint32_t *totals, uint32_t *lenhist) {
     __shared__ uint32_t se[1024], st[1024];
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     const uint32_t lm = (1u << lshift) - 1u;
@@ -265,16 +292,18 @@ k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshif
     uint32_t e = cnt, k = (cnt + lm) >> lshift;
     block_scan_1024(e, k, se, st);
     if (threadIdx.x == 1023u) { blk[2 * blockIdx.x] = e; blk[2 * blockIdx.x + 1] = k; }
-}
-__global__ void __launch_bounds__(1024)
-k_msm_scan_top(uint32_t *__restrict__ blk, uint32_t nblk, uint32_t NB, uint32_t *__restrict__ taskoff, uint32_t *totals) {
-    __shared__ uint32_t se[1024], st[1024];
-    const uint32_t t = threadIdx.x;
-    uint32_t e0 = t < nblk ? blk[2 * t] : 0u, k0 = t < nblk ? blk[2 * t + 1] : 0u;
-    uint32_t e = e0, k = k0;
+    if (!last_block_done(ticket, gridDim.x)) return;
+    // exclusive scan of the block totals (the former k_msm_scan_top)
+    const uint32_t t = threadIdx.x, nblk = gridDim.x;
+    volatile uint32_t *vb = blk;
+    uint32_t e0 = t < nblk ? vb[2 * t] : 0u, k0 = t < nblk ? vb[2 * t + 1] : 0u;
+    e = e0;
+    k = k0;
+    __syncthreads();
     block_scan_1024(e, k, se, st);
     if (t < nblk) { blk[2 * t] = e - e0; blk[2 * t + 1] = k - k0; }     // exclusive bases
-    if (t == 1023u) { taskoff[NB] = k; totals[0] = e; totals[1] = k; }
+    if (t == 1023u) { taskoff[NB] = k; totals[0] = e; totals[1] = k; totals[2] = 0u; totals[3] = 0u; }      // [2], [3]: split-bucket counters of k_msm_tasks
+    if (t < 4u * 65u + 4u) lenhist[t] = 0u;
 }
 __global__ void __launch_bounds__(1024)
 k_msm_scan_apply(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, const uint32_t *__restrict__ blk,
@@ -302,20 +331,20 @@ k_msm_scan_apply(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshi
 //                                      and the bucket totals counts[g]
 //   k_msm_scatter    [slice x window]  rank inside (slice, bucket) by LDS atomic; position =
 //                                      offsets[g] + base + rank
-static constexpr uint32_t kSlice = 32768;
-static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit counters
 
+// WORDS: LDS words of the packed counters -- kLdsWords for the 16-bit windows, 4 096 (16 KB: two blocks per CU) while a window
+// has at most 8 192 buckets (c <= 13)
+template <uint32_t WORDS>
 __global__ void __launch_bounds__(1024)
 k_msm_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-           uint32_t *__restrict__ hist16, uint32_t slice0, const uint32_t *__restrict__ only_if = nullptr) {
-    __shared__ uint32_t h[kLdsWords];
-    if (only_if && !*only_if) return;                 // the partitioned sort took this plan (k_sort_*): nothing to do
+           uint32_t *__restrict__ hist16, uint32_t slice0) {
+    __shared__ uint32_t h[WORDS];
     const uint32_t slice = slice0 + blockIdx.x, w = blockIdx.y;
     const uint32_t nbw = (w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B;
     const uint32_t words = (nbw + 1u) / 2u;
     for (uint32_t t = threadIdx.x; t < words; t += 1024u) h[t] = 0;
     __syncthreads();
-    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    const uint32_t lo = slice * pl.slice, hi = min(lo + pl.slice, pl.n);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
         const uint32_t v = digits[(size_t)w * pl.n + i];
         if (v) { const uint32_t b = (v >> 1) - 1u; atomicAdd(&h[b >> 1], 1u << (16u * (b & 1u))); }
@@ -346,12 +375,11 @@ k_msm_slicescan(const uint32_t *__restrict__ hist16, MsmPlan pl, uint32_t nslice
     if (2u * pair + 1u < nbw) counts[(size_t)w * pl.B + 2u * pair + 1u] = run1;
 }
 
+template <uint32_t WORDS>
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t nbmax,
-              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries, uint32_t passes,
-              const uint32_t *__restrict__ only_if = nullptr) {
-    __shared__ uint32_t h[kLdsWords];
-    if (only_if && !*only_if) return;
+              const uint32_t *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ entries, uint32_t passes) {
+    __shared__ uint32_t h[WORDS];
     // XCD-aware block order (speed only): blocks are dealt round-robin over the 8 XCDs, so block ids
     // with equal id % 8 share an L2.  All slices of a window go to one such group: the window's
     // entries region (4 B x n, 4 MB at 2^20) is then filled from one L2, where the 4-byte stores of
@@ -366,7 +394,7 @@ k_msm_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices,
     __syncthreads();
     const uint32_t *brow = base + ((size_t)w * nslices + slice) * nbmax;
     const uint32_t *orow = offsets + (size_t)w * pl.B;
-    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    const uint32_t lo = slice * pl.slice, hi = min(lo + pl.slice, pl.n);
     // The window's entries region (4 B x n: 4 MB at 2^20) is as large as the XCD's whole L2, so with the
     // streamed digit / offset rows passing through the same cache the 4-byte stores left as partial
     // lines (610 MB written for 67 MB of entries).  The slice is therefore scanned `passes` times, each
@@ -409,11 +437,10 @@ __global__ void __launch_bounds__(1024)
 k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ chist, uint32_t *__restrict__ heavy) {
     __shared__ uint32_t h[kMaxParts];
     const uint32_t slice = blockIdx.x, w = blockIdx.y;
-    if (slice == 0 && w == 0 && threadIdx.x == 0) *heavy = 0;        // raised by k_sort_coarse_scan (next launch)
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
     if (threadIdx.x < kMaxParts) h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    const uint32_t lo = slice * pl.slice, hi = min(lo + pl.slice, pl.n);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
         const uint32_t v = digits[(size_t)w * pl.n + i];
         if (v) atomicAdd(&h[((v >> 1) - 1u) >> kFineBits], 1u);
@@ -422,7 +449,8 @@ k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nsl
     if (threadIdx.x < parts) chist[((size_t)w * kMaxParts + threadIdx.x) * nslices + slice] = h[threadIdx.x];
 }
 __global__ void __launch_bounds__(1024)
-k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ wtotal, uint32_t *__restrict__ heavy) {
+k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *wtotal, uint32_t *__restrict__ heavy, uint32_t *ticket,
+                   uint32_t *__restrict__ wbase) {
     __shared__ uint32_t sm[1024];
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
@@ -449,28 +477,31 @@ k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, u
         const uint32_t size = (p + 1u < parts ? row[(size_t)(p + 1u) * nslices] : total) - row[(size_t)p * nslices];
         if (size > limit) atomicOr(heavy, 1u);
     }
-}
-__global__ void __launch_bounds__(64)
-k_sort_window_bases(const uint32_t *__restrict__ wtotal, int W, uint32_t *__restrict__ wbase) {
-    const uint32_t i = threadIdx.x;
-    uint32_t v = (int)i < W ? wtotal[i] : 0u, incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off, 64);
-        if ((int)i >= off) incl += o;
+    // round 4: the exclusive prefix of the window totals (k_sort_window_bases, a launch of its own before) in the last block to finish
+    if (!last_block_done(ticket, gridDim.x)) return;
+    if (t < 64u) {
+        const int W = pl.W;
+        volatile uint32_t *vt = wtotal;
+        uint32_t v = (int)t < W ? vt[t] : 0u, incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if ((int)t >= off) incl += o;
+        }
+        if ((int)t <= W) wbase[t] = incl - v;                        // wbase[W] = all entries
     }
-    if ((int)i <= W) wbase[i] = incl - v;                         // wbase[W] = all entries
 }
-static constexpr uint32_t kStageEntries = kSlice;                // a slice's entries staged in LDS: 128 KB
+// STAGE: entries of a slice staged in LDS (>= pl.slice): 16 384 = 64 KB, two blocks per CU
+template <uint32_t STAGE>
 __global__ void __launch_bounds__(1024)
 k_sort_coarse_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
                       const uint32_t *__restrict__ wbase, uint32_t *__restrict__ centries, const uint32_t *__restrict__ heavy) {
-    __shared__ uint32_t cnt[kMaxParts], start[kMaxParts + 1], stage[kStageEntries];
+    __shared__ uint32_t cnt[kMaxParts], start[kMaxParts + 1], stage[STAGE];
     if (*heavy) return;
     const uint32_t slice = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
     if (t < kMaxParts) cnt[t] = 0;
     __syncthreads();
-    const uint32_t lo = slice * kSlice, hi = min(lo + kSlice, pl.n);
+    const uint32_t lo = slice * pl.slice, hi = min(lo + pl.slice, pl.n);
     for (uint32_t i = lo + t; i < hi; i += 1024u) {
         const uint32_t v = digits[(size_t)w * pl.n + i];
         if (v) atomicAdd(&cnt[((v >> 1) - 1u) >> kFineBits], 1u);
@@ -511,10 +542,13 @@ __global__ void __launch_bounds__(512)
 k_sort_fine(const uint32_t *__restrict__ centries, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
             const uint32_t *__restrict__ wbase, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, const uint32_t *__restrict__ heavy) {
     __shared__ uint32_t fh[kFine], fstart[kFine + 1], stage[kFineStage];
-    if (*heavy) return;
     const uint32_t part = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
     if (part >= parts) return;
+    if (*heavy) {               // degenerate input: the host re-runs the call with the direct scatter; until then every bucket is empty
+        if (t < kFine) counts[(size_t)w * pl.B + (size_t)part * kFine + t] = 0u;
+        return;
+    }
     const uint32_t *crow = chist + (size_t)w * kMaxParts * nslices;
     const uint32_t begin = wbase[w] + crow[(size_t)part * nslices];
     const uint32_t end = part + 1u < parts ? wbase[w] + crow[(size_t)(part + 1u) * nslices] : wbase[w + 1];
@@ -547,12 +581,40 @@ k_sort_fine(const uint32_t *__restrict__ centries, MsmPlan pl, uint32_t nslices,
     }
 }
 
+__device__ __forceinline__ void task_scan_wave(const volatile uint32_t *lenhist, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges) {
+    // lane i owns length 64 - i (longest first); exclusive prefix over lanes, the second set behind the first.
+    // ranges: [0, n0) = slots of the first set, [n0, n0 + n1) = slots of the second
+    const uint32_t i = threadIdx.x;
+    uint32_t base = 0;
+    for (uint32_t set = 0; set < 2; set++) {
+        uint32_t v = lenhist[set * 65u + 64 - i], incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(incl, off, 64);
+            if ((int)i >= off) incl += o;
+        }
+        lenoff[set * 65u + 64 - i] = base + incl - v;
+        if (i == 0) lenoff[set * 65u] = 0;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (i == 0) { ranges[2 * set] = base; ranges[2 * set + 1] = base + total; }
+        base += total;
+    }
+}
+// Layout of Engine::scan_blk (32-bit words): block totals of the bucket scan | task-length histograms (two sets of 65) | their offsets |
+// slot ranges of the two sets | window totals | window bases | "last block" tickets of k_sort_coarse_scan, k_msm_scan_sums, k_msm_tasks
+static constexpr uint32_t kLenHist = 2048, kLenOff = kLenHist + 130, kRanges = kLenOff + 130, kWTotal = kRanges + 4, kWBase = kWTotal + 64,
+                          kTickets = kWBase + 68, kScanBlkWords = kTickets + 4;
+// the tickets return to 0 at the end of every launch that uses them; a fresh allocation has to be cleared once
+static hipError_t init_tickets(Engine *e, hipStream_t s) {
+    if (!e->scan_blk.fresh) return hipSuccess;
+    e->scan_blk.fresh = false;
+    return hipMemsetAsync(static_cast<uint32_t *>(e->scan_blk.p) + kTickets, 0, 16, s);
+}
 static constexpr uint32_t kTaskItems = 1024;          // buckets / tasks per block of k_msm_tasks / k_msm_task_perm
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
             uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts,
-            uint32_t *__restrict__ lenhist, uint32_t gshift, uint32_t split_g,
+            uint32_t *lenhist, uint32_t gshift, uint32_t split_g, uint32_t *ticket, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges,
             uint32_t *__restrict__ task_bucket = nullptr, Xyzz<FpL> *__restrict__ bacc = nullptr, uint32_t first_shard = 0u) {
     // bucket accumulators (the c = 16 two-level plans, round 4): task_bucket[t] = bucket << 1 | "first task of its bucket" -- the
     // accumulate adds a bucket's first task onto bacc[bucket], the running sum over the record shards of the call, instead of
@@ -590,6 +652,9 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
     }
     __syncthreads();
     if (threadIdx.x < 130 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
+    // round 4: the one-wave scan of the length classes (a launch of its own before) runs in the last block to finish
+    if (!last_block_done(ticket, gridDim.x)) return;
+    if (threadIdx.x < 64) task_scan_wave((const volatile uint32_t *)lenhist, lenoff, ranges);
 }
 
 
@@ -597,25 +662,6 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
 // a wave of k_msm_accum runs for the longest of its 64 tasks (~70 % lane utilisation at 2^20).
 // Counting sort on the length class ceil(len / (L/64)) in [1, 64]: per-block LDS histogram -> 64 global counters -> a one-wave
 // scan -> per-block range reservation -> permutation.
-__global__ void __launch_bounds__(64)
-k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges) {
-    // lane i owns length 64 - i (longest first); exclusive prefix over lanes, the second set behind the first.
-    // ranges: [0, n0) = slots of the first set, [n0, n0 + n1) = slots of the second
-    const uint32_t i = threadIdx.x;
-    uint32_t base = 0;
-    for (uint32_t set = 0; set < 2; set++) {
-        uint32_t v = lenhist[set * 65u + 64 - i], incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t o = __shfl_up(incl, off, 64);
-            if ((int)i >= off) incl += o;
-        }
-        lenoff[set * 65u + 64 - i] = base + incl - v;
-        if (i == 0) lenoff[set * 65u] = 0;
-        const uint32_t total = __shfl(incl, 63, 64);
-        if (i == 0) { ranges[2 * set] = base; ranges[2 * set + 1] = base + total; }
-        base += total;
-    }
-}
 __global__ void __launch_bounds__(256)
 k_msm_task_perm(const Task *__restrict__ tasks, const uint32_t *__restrict__ totals, uint32_t *__restrict__ lenoff,
                 uint32_t *__restrict__ perm, uint32_t gshift, const uint32_t *__restrict__ taskoff, uint32_t split_g) {
@@ -1430,6 +1476,7 @@ static int launch_two_level(Engine *e, const MsmPlan &pl, size_t ns, uint32_t ls
         else hipLaunchKernelGGL(k_msm_rowcol<64u>, dim3(blocks), dim3(256), 0, st, (const Xyzz<FpL> *)a.bacc, pl.B, w0, a.rc);
     };
     // stream3, beside the main accumulate (a launch of TB's ~770 waves alone would be a latency chain on an empty chip: 0.25 ms lost)
+    HIPCHK(e->need_stream3());
     hipStream_t s3 = e->stream3;
     HIPCHK(hipEventRecord(e->ev_j3, s));
     HIPCHK(hipStreamWaitEvent(s3, e->ev_j3, 0));
@@ -1478,7 +1525,7 @@ template <> struct ReduceCfg<Fp2> { static constexpr bool kFourLane = true; stat
 // (3.2 ms at the link's ~53 GB/s) is as long as the whole device pipeline; round 3 ran the shards as independent pipelines
 // (k sorts, k reduces over the same 557 056 buckets, k host tails: profiles/r03_h2d_pipeline.txt).
 template <class F>
-static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override) {
+static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial_words, int c_override, bool direct_sort = false) {
     ShardFeed feed = e->feed;                   // (a staged call's cut; consumed here whatever happens below)
     e->feed.k = 0;
     const void *host_src = e->host_src;
@@ -1567,25 +1614,29 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->pts.reserve((size_t)ns_max * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
-    const uint32_t nslices_max = (uint32_t)(((size_t)ns_max + kSlice - 1) / kSlice);
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
     HIPCHK(e->digits.reserve((size_t)pl.W * ns_max * 4));                          // digits [W][ns]
     // c = 16 plans below 2^24 records: the partitioned sort (k_sort_*); EIP2537_SORT2=0 or any other plan: direct scatter
     static const bool env_sort2 = [] { const char *v = getenv("EIP2537_SORT2"); return !v || atoi(v) != 0; }();
-    const bool sort2 = env_sort2 && pl.c == 16 && ns_max < (1u << 24) && (pl.B % kFine) == 0 && (pl.BT % kFine) == 0 &&
+    const bool sort2 = env_sort2 && !direct_sort && pl.c == 16 && ns_max < (1u << 24) && (pl.B % kFine) == 0 && (pl.BT % kFine) == 0 &&
                        (std::max(pl.B, pl.BT) >> kFineBits) <= kMaxParts && pl.W < 64;
     // hist16: [W][slices][nbmax] packed slice histograms (direct scatter) | [W][parts][slices] partition counts (partitioned sort);
-    // slice_base: [W][slices][nbmax] prefix over the slices | the entries in partition order.
-    // A sort2 plan keeps room for both forms: a degenerate input is handed to the direct scatter on the device (kHeavyFactor).
-    HIPCHK(e->hist16.reserve(std::max((size_t)pl.W * nslices_max * (nbmax / 2) * 4, sort2 ? (size_t)pl.W * kMaxParts * nslices_max * 4 : (size_t)0)));
-    HIPCHK(e->slice_base.reserve(std::max((size_t)pl.W * nslices_max * nbmax * 4, sort2 ? (size_t)pl.W * ns_max * 4 : (size_t)0)));
+    // slice_base: [W][slices][nbmax] prefix over the slices | the entries in partition order.  Slices: msm_slice_for, per shard.
+    size_t hist_bytes = 0, base_bytes = 0;
+    for (int sh = 0; sh < K; sh++) {
+        const uint32_t ns = feed.bound[sh + 1] - feed.bound[sh], sl = msm_slice_for(ns, pl.W, sort2), nsl = (ns + sl - 1u) / sl;
+        hist_bytes = std::max(hist_bytes, sort2 ? (size_t)pl.W * kMaxParts * nsl * 4 : (size_t)pl.W * nsl * (nbmax / 2) * 4);
+        base_bytes = std::max(base_bytes, sort2 ? (size_t)pl.W * ns * 4 : (size_t)pl.W * nsl * nbmax * 4);
+    }
+    HIPCHK(e->hist16.reserve(hist_bytes));
+    HIPCHK(e->slice_base.reserve(base_bytes));
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve((size_t)pl.W * ns_max * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4 + 2 * 64 * 4 + 16));     // scan block totals + task-length histograms / offsets (two sets) + slot ranges + window totals / bases
+    HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases, tickets
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if (two_level) {
@@ -1600,6 +1651,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
     auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
     HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
+    uint32_t *heavy = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 8);        // raised by k_sort_coarse_scan: degenerate input
+    HIPCHK(hipMemsetAsync(heavy, 0, 8, s));
+    HIPCHK(init_tickets(e, s));
 
     const size_t rec_words = Wire<F>::kMsmRecWords, rec_bytes = rec_words * 4;
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
@@ -1616,7 +1670,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
+    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges, *tickets = blk + kTickets;
     uint32_t *taskbkt = two_level ? reinterpret_cast<uint32_t *>(e->taskbkt.p) : nullptr;
     Xyzz<FpL> *bacc = two_level ? reinterpret_cast<Xyzz<FpL> *>(e->bacc.p) : nullptr;
     PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
@@ -1632,6 +1686,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     bool inline_copies = false;
     if (staged) {
+        HIPCHK(e->need_stream2());
         for (int sh = 0; sh < K; sh++)
             if (!e->ev_copy[sh]) HIPCHK(hipEventCreateWithFlags(&e->ev_copy[sh], hipEventDisableTiming));
         // the helper thread copies; without one (no thread to be had) this thread copies each shard itself in front of its kernels
@@ -1649,7 +1704,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         ps.L = 1u << lshift;
         ps.max_entries = (uint64_t)ns * pl.W;
         ps.max_tasks = (uint32_t)(pl.NB + (ps.max_entries >> lshift) + 1u);
-        const uint32_t nslices = (ns + kSlice - 1u) / kSlice, rec_blocks = (ns + 255u) / 256u;
+        ps.slice = msm_slice_for(ns, pl.W, sort2);
+        const uint32_t nslices = (ns + ps.slice - 1u) / ps.slice, rec_blocks = (ns + 255u) / 256u;
+        const bool small_lds = nbmax <= 8192u;             // direct scatter: 16 KB of packed counters are enough (c <= 13)
         const uint32_t scatter_passes = env_sp ? env_sp : (ns >= (1u << 19) ? 4u : ns >= (1u << 18) ? 2u : 1u);   // measured: profiles/r02_scatter_passes.txt
         const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in) + (size_t)r0 * rec_words;
         const uint32_t split_g = last ? split_top : 0xffffffffu;          // earlier shards: one task order, one accumulate launch
@@ -1667,36 +1724,32 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             if (e->copy_gate) e->copy_gate->done(e->copy_turn);            // shards of one call on one device copy in shard order (api.hip); a pageable copy returns when its last chunk is staged
             HIPCHK(ce);
         }
-        HIPCHK(hipMemsetAsync(totals, 0, 16, s));            // [0] entries [1] tasks [2] lightly split [3] heavily split
+        // totals: [0] entries [1] tasks [2] lightly split [3] heavily split buckets -- written / cleared by k_msm_scan_sums' last block
         hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, ps, pts, ptl, digits, err, r0);
-        if (!sort2) hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
+        if (!sort2 && small_lds) hipLaunchKernelGGL(k_msm_hist<4096u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
+        else if (!sort2) hipLaunchKernelGGL(k_msm_hist<kLdsWords>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
         const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
-        uint32_t *heavy = nullptr;
         if (sort2) {
-            uint32_t *wtotal = blk + 2048 + 264, *wbase = wtotal + 64;
-            heavy = wbase + 64;
+            // a degenerate input (k_sort_coarse_scan raises `heavy`) leaves every bucket empty here; the host then re-runs the call with
+            // the direct scatter (below).  Round 3 launched the direct-scatter kernels behind these with the flag as their condition:
+            // three empty launches (17 us) in every shard of every ordinary call.
+            uint32_t *wtotal = blk + kWTotal, *wbase = blk + kWBase;
             hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, heavy);
-            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy);
-            hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
-            hipLaunchKernelGGL(k_sort_coarse_scatter, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy, tickets + 0, wbase);
+            hipLaunchKernelGGL(k_sort_coarse_scatter<16384u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
             hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, ps, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
-            // the direct scatter, only when the flag is up (degenerate input)
-            hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u, (const uint32_t *)heavy);
-            hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts, (const uint32_t *)heavy);
         } else {
             hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts);
         }
-        HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
-        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
-        hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
+        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, tickets + 1, taskoff, totals, lenhist);
         hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-        if (!sort2 || heavy)
-            hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes,
-                               (const uint32_t *)heavy);
+        if (!sort2 && small_lds)
+            hipLaunchKernelGGL(k_msm_scatter<4096u>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
+        else if (!sort2)
+            hipLaunchKernelGGL(k_msm_scatter<kLdsWords>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
         hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                           split_small, split_big, totals + 2, lenhist, gshift, split_g, taskbkt, bacc, first_shard);
+                           split_small, split_big, totals + 2, lenhist, gshift, split_g, tickets + 2, lenoff, ranges, taskbkt, bacc, first_shard);
         const uint32_t task_blocks = (ps.max_tasks + 255u) / 256u;
-        hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
         hipLaunchKernelGGL(k_msm_task_perm, dim3((ps.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
         if (last) HIPCHK(hipEventRecord(e->ev_a, s));
         if (two_level) {
@@ -1716,14 +1769,21 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
-    unsigned long long herr = 0;
+    unsigned long long herr2[2] = {0, 0};       // first-error word | `heavy` flag
+    unsigned long long &herr = herr2[0];
     std::vector<Xyzz<F>> hw(nwin_out);
     StreamDrain drain{s};
-    HIPCHK(hipMemcpyAsync(&herr, err, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(herr2, err, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hw.data(), winout + (dev_winsum ? red_blocks : 0u), nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     drain.armed = false;
     staged_copy.finish();                       // (the helper has long finished: every copy event was waited for above)
+    if (sort2 && (uint32_t)herr2[1] != 0u && herr == ~0ull) {
+        // degenerate input (a partition above kHeavyFactor times its window's mean, e.g. all scalars equal): the partitioned sort
+        // stood down on the device and the buckets above are empty.  The records are all in HBM by now: run the call again with the
+        // direct scatter, which spreads a heavy bucket over its 32 768-record slices (profiles/r04_degenerate_inputs.txt).
+        return msm_device_t<F>(e, d_in, n, partial_words, c_override, true);
+    }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;
@@ -1923,7 +1983,8 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     pl.L = 1u << lshift;
     pl.max_tasks = (uint32_t)(pl.NB + pl.max_entries / pl.L + 1);
     const uint32_t units = (uint32_t)pl.W * (uint32_t)M;
-    const uint32_t nslices = (uint32_t)((n + kSlice - 1) / kSlice);
+    pl.slice = msm_slice_for((uint32_t)n, pl.W, false);
+    const uint32_t nslices = (uint32_t)((n + pl.slice - 1) / pl.slice);
     const uint32_t nbmax = pl.B;
     if (nbmax > 2u * kLdsWords) return E_MEMORY_ERROR;         // LDS histogram: 65536 packed counters
     // G1: the whole batch pipeline in limb form (limb30.h), like the single-call plans of the same size
@@ -1941,7 +2002,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve((size_t)units * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64 + (size_t)(M + 1) * 4 + (size_t)M * 8));
-    HIPCHK(e->scan_blk.reserve(2 * 1024 * 4 + (4 * 65 + 4) * 4));
+    HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
@@ -1952,7 +2013,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     auto *err = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->misc.p) + 64);        // [M]
     auto *d_coff = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 64 + (size_t)M * 8);   // [M + 1]
     HIPCHK(hipMemsetAsync(err, 0xFF, (size_t)M * 8, s));
-    HIPCHK(hipMemsetAsync(totals, 0, 16, s));
+    HIPCHK(init_tickets(e, s));
     HIPCHK(hipMemcpyAsync(d_coff, coff, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
@@ -1967,7 +2028,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + 2048, *lenoff = blk + 2048 + 130, *ranges = blk + 2048 + 260;
+    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges, *tickets = blk + kTickets;
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     {
@@ -1981,18 +2042,17 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     HIPCHK(hipEventRecord(e->ev_start, s));
     PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
     hipLaunchKernelGGL(k_msm_decode_batch<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, real, (uint32_t)n, d_coff, M, pts, ptl, digits, err);
-    hipLaunchKernelGGL(k_msm_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
+    if (nbmax <= 8192u) hipLaunchKernelGGL(k_msm_hist<4096u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
+    else hipLaunchKernelGGL(k_msm_hist<kLdsWords>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;
-    HIPCHK(hipMemsetAsync(lenhist, 0, (4 * 65 + 4) * 4, s));
-    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
-    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals);
+    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, tickets + 1, taskoff, totals, lenhist);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
+    if (nbmax <= 8192u) hipLaunchKernelGGL(k_msm_scatter<4096u>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
+    else hipLaunchKernelGGL(k_msm_scatter<kLdsWords>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2, lenhist, gshift, 0xffffffffu);
+                       split_small, split_big, totals + 2, lenhist, gshift, 0xffffffffu, tickets + 2, lenoff, ranges);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
-    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
     hipLaunchKernelGGL(k_msm_task_perm, dim3((pl.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, 0xffffffffu);
     HIPCHK(hipEventRecord(e->ev_a, s));
     launch_accum(s, task_blocks, true, pts, ptl, entries, tasks, perm, totals, partial);          // two lanes per task

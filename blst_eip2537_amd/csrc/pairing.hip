@@ -470,6 +470,7 @@ static int pairing_front(Engine *e, const uint32_t *in, size_t k, const uint32_t
     hipLaunchKernelGGL(k_pair_decode, dim3((uint32_t)((2 * k + 255) / 256)), dim3(256), 0, s, in, (uint32_t)k, b.pl, b.ql, b.flagP, b.flagQ, b.err, cm);
     HIPCHK(hipEventRecord(e->ev_j3, s));
     // fork: the G1 membership kernel runs beside the line walk
+    HIPCHK(e->need_stream2());
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_j3, 0));
     if (excl)
         hipLaunchKernelGGL(k_pair_check_g1<true>, dim3(check_blocks), dim3(64), 0, e->stream2, b.pl, b.flagP, (uint32_t)k, b.err, cm);

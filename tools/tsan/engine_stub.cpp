@@ -23,6 +23,7 @@ template <class F> static int msm_stub(Engine *e, const void *d_in, size_t n, Xy
         // before it "launches" (here: reads) that shard
         for (int sh = 0; sh < feed.k; sh++)
             if (!e->ev_copy[sh] && hipEventCreateWithFlags(&e->ev_copy[sh], hipEventDisableTiming) != hipSuccess) return E_MEMORY_ERROR;
+        if (e->need_stream2() != hipSuccess) return E_MEMORY_ERROR;
         const void *src = e->host_src;
         e->host_src = nullptr;
         const bool threaded = staged.start(e->helper, e->device, e->stream2, e->ev_copy, feed, Wire<F>::kMsmRecWords * 4, e->input.p, src);
