@@ -48,6 +48,8 @@ static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit cou
 // scatter on 40 blocks (66 of its 143 us of sort stage) and a 245 760-record shard of a staged call its coarse scatter on 128 blocks
 // of one per CU (45 us; the whole 2^20: 102 us in two rounds).  Now: the power of two that gives the windows ~512 blocks in all.
 static uint32_t msm_slice_for(uint32_t n, int W, bool sort2) {
+    static const uint32_t env = [] { const char *v = getenv("EIP2537_SORT_SLICE"); return v ? (uint32_t)atoi(v) : 0u; }();     // A/B
+    if (env >= 1024u && env <= kSlice && (env & (env - 1u)) == 0u) return env;
     uint32_t want = (uint32_t)(((uint64_t)n * (uint64_t)W + 511u) / 512u), s = sort2 ? 4096u : 2048u;
     const uint32_t cap = sort2 ? 16384u : kSlice;
     while (s < want && s < cap) s <<= 1;
@@ -1736,7 +1738,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             uint32_t *wtotal = blk + kWTotal, *wbase = blk + kWBase;
             hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, heavy);
             hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy, tickets + 0, wbase);
-            hipLaunchKernelGGL(k_sort_coarse_scatter<16384u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+            if (ps.slice <= 16384u)
+                hipLaunchKernelGGL(k_sort_coarse_scatter<16384u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+            else
+                hipLaunchKernelGGL(k_sort_coarse_scatter<kSlice>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
             hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, ps, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
         } else {
             hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts);
@@ -1954,12 +1959,8 @@ static void launch_reduce_batch(hipStream_t s, uint32_t units, bool limb, const 
     else hipLaunchKernelGGL((k_msm_reduce_batch<Fp, 1>), grid, dim3(256), 0, s, partial, taskoff, units, winout);
 }
 static void launch_reduce_batch(hipStream_t s, uint32_t units, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff, Xyzz<Fp2> *winout) {
-    static const bool four = [] { const char *v = getenv("EIP2537_BATCH_G2_4LANE"); return v && atoi(v) != 0; }();      // A/B: the replicated 4-lane form of round 2
-    if (four) {
-        if (units * 4u <= 1024u) hipLaunchKernelGGL((k_msm_reduce_batch<Fp2, 4>), dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
-        else hipLaunchKernelGGL((k_msm_reduce_batch<Fp2, 1>), dim3((units + 3u) / 4u), dim3(256), 0, s, partial, taskoff, units, winout);
-        return;
-    }
+    // (round 4: the replicated 4-lane form k_msm_reduce_batch<Fp2, *> of round 2 -- 512 registers + 800 B of scratch per lane, kept behind
+    // an A/B switch in round 3 -- is no longer instantiated)
     if (units * 4u <= 1024u) hipLaunchKernelGGL(k_msm_reduce_batch8c<4>, dim3(units), dim3(256), 0, s, partial, taskoff, units, winout);
     else hipLaunchKernelGGL(k_msm_reduce_batch8c<1>, dim3((units + 3u) / 4u), dim3(256), 0, s, partial, taskoff, units, winout);
 }

@@ -19,3 +19,18 @@ for name, inp in cases.items():
     for _ in range(3):
         X.dev_call("eip2537_hip_g1multiexp_dev", d.data_ptr(), n)
     print("%-22s n=2^18: %.2f ms per call" % (name, (time.perf_counter() - t) / 3 * 1e3), flush=True)
+
+# G2 (round 4): all scalars equal sends a whole window to ONE bucket, i.e. through k_msm_fold_big<Fp2, Fp2> -- the one kernel with a
+# large scratch frame (944 B per lane) that an adversarial input can reach
+n2 = 1 << 16
+base2 = X.gen_msm_input("g2", n2, A, B, 5)
+cases2 = {"G2 random (reference)": base2,
+          "G2 all scalars equal": b"".join(base2[i * 288:i * 288 + 256] + k for i in range(n2)),
+          "G2 all records equal": (base2[:256] + k) * n2}
+for name, inp in cases2.items():
+    d = torch.frombuffer(bytearray(inp), dtype=torch.uint8).cuda()
+    X.dev_call("eip2537_hip_g2multiexp_dev", d.data_ptr(), n2)
+    t = time.perf_counter()
+    for _ in range(3):
+        X.dev_call("eip2537_hip_g2multiexp_dev", d.data_ptr(), n2)
+    print("%-22s n=2^16: %.2f ms per call" % (name, (time.perf_counter() - t) / 3 * 1e3), flush=True)
