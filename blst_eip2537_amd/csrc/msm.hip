@@ -46,13 +46,15 @@ static constexpr uint32_t kSlice = 32768;             // largest slice of the co
 static constexpr uint32_t kLdsWords = 32768;          // 65536 packed 16-bit counters
 // Records per (slice, window) block of the counting-sort kernels.  Round 3 used 32 768 everywhere: a 2^16-record call then ran its
 // scatter on 40 blocks (66 of its 143 us of sort stage) and a 245 760-record shard of a staged call its coarse scatter on 128 blocks
-// of one per CU (45 us; the whole 2^20: 102 us in two rounds).  Now: the power of two that gives the windows ~512 blocks in all.
+// (45 us for a quarter of the records the whole 2^20 sorts in 102).
 static uint32_t msm_slice_for(uint32_t n, int W, bool sort2) {
     static const uint32_t env = [] { const char *v = getenv("EIP2537_SORT_SLICE"); return v ? (uint32_t)atoi(v) : 0u; }();     // A/B
     if (env >= 1024u && env <= kSlice && (env & (env - 1u)) == 0u) return env;
-    uint32_t want = (uint32_t)(((uint64_t)n * (uint64_t)W + 511u) / 512u), s = sort2 ? 4096u : 2048u;
-    const uint32_t cap = sort2 ? 16384u : kSlice;
-    while (s < want && s < cap) s <<= 1;
+    // the largest slice that still gives the W windows ~256 blocks in all (2^20 records at c = 16: 32 768 -> 512 blocks, measured
+    // better than 8 192 -> 2 048 blocks: 0.558 against 0.612 ms of sort stage; profiles/r04_sort_stage.txt)
+    uint32_t s = kSlice;
+    const uint32_t floor_ = sort2 ? 4096u : 2048u;
+    while (s > floor_ && (uint64_t)((n + s - 1u) / s) * (uint64_t)W < 256u) s >>= 1;
     return s;
 }
 
@@ -250,8 +252,9 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
     });
 }
 
-// Two-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
-//   k_msm_scan_sums  [1024 buckets per block]  block totals of (entries, tasks); its last block scans the block totals
+// Three-launch exclusive scan over the bucket histogram (<= 1024 x 1024 buckets):
+//   k_msm_scan_sums  [1024 buckets per block]  block totals of (entries, tasks)
+//   k_msm_scan_top   [1 block]                 exclusive scan of the block totals
 //   k_msm_scan_apply [1024 buckets per block]  local scan + block base -> offsets, taskoff
 __device__ __forceinline__ void block_scan_1024(uint32_t &e, uint32_t &k, uint32_t *se, uint32_t *st) {
     // inclusive Hillis-Steele scan of (e, k) over the 1024 threads of the block
@@ -269,24 +272,11 @@ __device__ __forceinline__ void block_scan_1024(uint32_t &e, uint32_t &k, uint32
     e = se[t];
     k = st[t];
 }
-// (round 4: k_msm_scan_top was a launch of its own; the LAST block of k_msm_scan_sums to finish -- ticket counter at blk[2 * 1024] --
-// now runs it, and also clears the task-length histograms that k_msm_tasks fills next: two launches and one memset less per shard)
-__device__ __forceinline__ bool last_block_done(uint32_t *counter, uint32_t nblocks) {
-    __shared__ uint32_t s_ticket;
-    __threadfence();                                             // this block's results are visible before its ticket is
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(counter, 1u);
-    __syncthreads();
-    const bool last = s_ticket == nblocks - 1u;
-    if (last) {
-        __threadfence();
-        if (threadIdx.x == 0) *counter = 0u;                     // ready for the next launch
-    }
-    return last;
-}
+// (round 4, measured and reverted: running k_msm_scan_top / k_msm_task_scan / k_sort_window_bases in the LAST block of their producers --
+// ticket counter, __threadfence -- saved three 5-us launches and cost 0.15 ms per 2^20-record sort stage: a device-scope fence on this
+// multi-XCD part writes the XCD's L2 back, and every block of a 544-block grid paid for one.  profiles/r04_sort_stage.txt)
 __global__ void __launch_bounds__(1024)
-k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, uint32_t *blk, uint32_t *ticket,
-                uint32_t *taskoff, uint32_t *totals, uint32_t *lenhist) {
+k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshift, uint32_t *__restrict__ blk) {
     __shared__ uint32_t se[1024], st[1024];
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     const uint32_t lm = (1u << lshift) - 1u;
@@ -294,17 +284,18 @@ k_msm_scan_sums(const uint32_t *__restrict__ counts, uint32_t NB, uint32_t lshif
     uint32_t e = cnt, k = (cnt + lm) >> lshift;
     block_scan_1024(e, k, se, st);
     if (threadIdx.x == 1023u) { blk[2 * blockIdx.x] = e; blk[2 * blockIdx.x + 1] = k; }
-    if (!last_block_done(ticket, gridDim.x)) return;
-    // exclusive scan of the block totals (the former k_msm_scan_top)
-    const uint32_t t = threadIdx.x, nblk = gridDim.x;
-    volatile uint32_t *vb = blk;
-    uint32_t e0 = t < nblk ? vb[2 * t] : 0u, k0 = t < nblk ? vb[2 * t + 1] : 0u;
-    e = e0;
-    k = k0;
-    __syncthreads();
+}
+// also clears what k_msm_tasks accumulates into next (round 3: two memsets per call): the split-bucket counters totals[2], [3] and the
+// task-length histograms
+__global__ void __launch_bounds__(1024)
+k_msm_scan_top(uint32_t *__restrict__ blk, uint32_t nblk, uint32_t NB, uint32_t *__restrict__ taskoff, uint32_t *totals, uint32_t *__restrict__ lenhist) {
+    __shared__ uint32_t se[1024], st[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t e0 = t < nblk ? blk[2 * t] : 0u, k0 = t < nblk ? blk[2 * t + 1] : 0u;
+    uint32_t e = e0, k = k0;
     block_scan_1024(e, k, se, st);
     if (t < nblk) { blk[2 * t] = e - e0; blk[2 * t + 1] = k - k0; }     // exclusive bases
-    if (t == 1023u) { taskoff[NB] = k; totals[0] = e; totals[1] = k; totals[2] = 0u; totals[3] = 0u; }      // [2], [3]: split-bucket counters of k_msm_tasks
+    if (t == 1023u) { taskoff[NB] = k; totals[0] = e; totals[1] = k; totals[2] = 0u; totals[3] = 0u; }
     if (t < 4u * 65u + 4u) lenhist[t] = 0u;
 }
 __global__ void __launch_bounds__(1024)
@@ -451,8 +442,7 @@ k_sort_coarse_hist(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nsl
     if (threadIdx.x < parts) chist[((size_t)w * kMaxParts + threadIdx.x) * nslices + slice] = h[threadIdx.x];
 }
 __global__ void __launch_bounds__(1024)
-k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *wtotal, uint32_t *__restrict__ heavy, uint32_t *ticket,
-                   uint32_t *__restrict__ wbase) {
+k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, uint32_t *__restrict__ wtotal, uint32_t *__restrict__ heavy) {
     __shared__ uint32_t sm[1024];
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
@@ -479,18 +469,16 @@ k_sort_coarse_scan(uint32_t *__restrict__ chist, MsmPlan pl, uint32_t nslices, u
         const uint32_t size = (p + 1u < parts ? row[(size_t)(p + 1u) * nslices] : total) - row[(size_t)p * nslices];
         if (size > limit) atomicOr(heavy, 1u);
     }
-    // round 4: the exclusive prefix of the window totals (k_sort_window_bases, a launch of its own before) in the last block to finish
-    if (!last_block_done(ticket, gridDim.x)) return;
-    if (t < 64u) {
-        const int W = pl.W;
-        volatile uint32_t *vt = wtotal;
-        uint32_t v = (int)t < W ? vt[t] : 0u, incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 64);
-            if ((int)t >= off) incl += o;
-        }
-        if ((int)t <= W) wbase[t] = incl - v;                        // wbase[W] = all entries
+}
+__global__ void __launch_bounds__(64)
+k_sort_window_bases(const uint32_t *__restrict__ wtotal, int W, uint32_t *__restrict__ wbase) {
+    const uint32_t i = threadIdx.x;
+    uint32_t v = (int)i < W ? wtotal[i] : 0u, incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)i >= off) incl += o;
     }
+    if ((int)i <= W) wbase[i] = incl - v;                         // wbase[W] = all entries
 }
 // STAGE: entries of a slice staged in LDS (>= pl.slice): 16 384 = 64 KB, two blocks per CU
 template <uint32_t STAGE>
@@ -583,7 +571,8 @@ k_sort_fine(const uint32_t *__restrict__ centries, MsmPlan pl, uint32_t nslices,
     }
 }
 
-__device__ __forceinline__ void task_scan_wave(const volatile uint32_t *lenhist, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges) {
+__global__ void __launch_bounds__(64)
+k_msm_task_scan(const uint32_t *__restrict__ lenhist, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges) {
     // lane i owns length 64 - i (longest first); exclusive prefix over lanes, the second set behind the first.
     // ranges: [0, n0) = slots of the first set, [n0, n0 + n1) = slots of the second
     const uint32_t i = threadIdx.x;
@@ -602,21 +591,15 @@ __device__ __forceinline__ void task_scan_wave(const volatile uint32_t *lenhist,
     }
 }
 // Layout of Engine::scan_blk (32-bit words): block totals of the bucket scan | task-length histograms (two sets of 65) | their offsets |
-// slot ranges of the two sets | window totals | window bases | "last block" tickets of k_sort_coarse_scan, k_msm_scan_sums, k_msm_tasks
+// slot ranges of the two sets | window totals | window bases
 static constexpr uint32_t kLenHist = 2048, kLenOff = kLenHist + 130, kRanges = kLenOff + 130, kWTotal = kRanges + 4, kWBase = kWTotal + 64,
-                          kTickets = kWBase + 68, kScanBlkWords = kTickets + 4;
-// the tickets return to 0 at the end of every launch that uses them; a fresh allocation has to be cleared once
-static hipError_t init_tickets(Engine *e, hipStream_t s) {
-    if (!e->scan_blk.fresh) return hipSuccess;
-    e->scan_blk.fresh = false;
-    return hipMemsetAsync(static_cast<uint32_t *>(e->scan_blk.p) + kTickets, 0, 16, s);
-}
+                          kScanBlkWords = kWBase + 68;
 static constexpr uint32_t kTaskItems = 1024;          // buckets / tasks per block of k_msm_tasks / k_msm_task_perm
 __global__ void __launch_bounds__(256)
 k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
             const uint32_t *__restrict__ taskoff, uint32_t NB, uint32_t lshift, Task *__restrict__ tasks,
             uint32_t *__restrict__ split_small, uint32_t *__restrict__ split_big, uint32_t *split_counts,
-            uint32_t *lenhist, uint32_t gshift, uint32_t split_g, uint32_t *ticket, uint32_t *__restrict__ lenoff, uint32_t *__restrict__ ranges,
+            uint32_t *__restrict__ lenhist, uint32_t gshift, uint32_t split_g,
             uint32_t *__restrict__ task_bucket = nullptr, Xyzz<FpL> *__restrict__ bacc = nullptr, uint32_t first_shard = 0u) {
     // bucket accumulators (the c = 16 two-level plans, round 4): task_bucket[t] = bucket << 1 | "first task of its bucket" -- the
     // accumulate adds a bucket's first task onto bacc[bucket], the running sum over the record shards of the call, instead of
@@ -654,9 +637,6 @@ k_msm_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ of
     }
     __syncthreads();
     if (threadIdx.x < 130 && h[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], h[threadIdx.x]);
-    // round 4: the one-wave scan of the length classes (a launch of its own before) runs in the last block to finish
-    if (!last_block_done(ticket, gridDim.x)) return;
-    if (threadIdx.x < 64) task_scan_wave((const volatile uint32_t *)lenhist, lenoff, ranges);
 }
 
 
@@ -1638,7 +1618,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>)));
     HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases, tickets
+    HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
     if (two_level) {
@@ -1655,7 +1635,6 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
     uint32_t *heavy = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 8);        // raised by k_sort_coarse_scan: degenerate input
     HIPCHK(hipMemsetAsync(heavy, 0, 8, s));
-    HIPCHK(init_tickets(e, s));
 
     const size_t rec_words = Wire<F>::kMsmRecWords, rec_bytes = rec_words * 4;
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
@@ -1672,7 +1651,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges, *tickets = blk + kTickets;
+    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges;
     uint32_t *taskbkt = two_level ? reinterpret_cast<uint32_t *>(e->taskbkt.p) : nullptr;
     Xyzz<FpL> *bacc = two_level ? reinterpret_cast<Xyzz<FpL> *>(e->bacc.p) : nullptr;
     PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
@@ -1737,7 +1716,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             // three empty launches (17 us) in every shard of every ordinary call.
             uint32_t *wtotal = blk + kWTotal, *wbase = blk + kWBase;
             hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, heavy);
-            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy, tickets + 0, wbase);
+            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy);
+            hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
             if (ps.slice <= 16384u)
                 hipLaunchKernelGGL(k_sort_coarse_scatter<16384u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
             else
@@ -1746,15 +1726,17 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         } else {
             hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts);
         }
-        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, tickets + 1, taskoff, totals, lenhist);
+        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
+        hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals, lenhist);
         hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
         if (!sort2 && small_lds)
             hipLaunchKernelGGL(k_msm_scatter<4096u>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
         else if (!sort2)
             hipLaunchKernelGGL(k_msm_scatter<kLdsWords>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
         hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                           split_small, split_big, totals + 2, lenhist, gshift, split_g, tickets + 2, lenoff, ranges, taskbkt, bacc, first_shard);
+                           split_small, split_big, totals + 2, lenhist, gshift, split_g, taskbkt, bacc, first_shard);
         const uint32_t task_blocks = (ps.max_tasks + 255u) / 256u;
+        hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
         hipLaunchKernelGGL(k_msm_task_perm, dim3((ps.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
         if (last) HIPCHK(hipEventRecord(e->ev_a, s));
         if (two_level) {
@@ -2014,7 +1996,6 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     auto *err = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->misc.p) + 64);        // [M]
     auto *d_coff = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 64 + (size_t)M * 8);   // [M + 1]
     HIPCHK(hipMemsetAsync(err, 0xFF, (size_t)M * 8, s));
-    HIPCHK(init_tickets(e, s));
     HIPCHK(hipMemcpyAsync(d_coff, coff, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
     const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in);
     auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
@@ -2029,7 +2010,7 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
     auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges, *tickets = blk + kTickets;
+    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges;
     auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
     uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
     {
@@ -2047,12 +2028,14 @@ static int msm_batch_device_t(Engine *e, const void *d_in, const uint32_t *coff,
     else hipLaunchKernelGGL(k_msm_hist<kLdsWords>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, pl, nslices, nbmax, hist16, 0u);
     hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, pl, nslices, nbmax, base, counts);
     const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;
-    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, tickets + 1, taskoff, totals, lenhist);
+    hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals, lenhist);
     hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
     if (nbmax <= 8192u) hipLaunchKernelGGL(k_msm_scatter<4096u>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     else hipLaunchKernelGGL(k_msm_scatter<kLdsWords>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, pl, nslices, nbmax, base, offsets, entries, scatter_passes);
     hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
-                       split_small, split_big, totals + 2, lenhist, gshift, 0xffffffffu, tickets + 2, lenoff, ranges);
+                       split_small, split_big, totals + 2, lenhist, gshift, 0xffffffffu);
+    hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
     const uint32_t task_blocks = (pl.max_tasks + 255u) / 256u;
     hipLaunchKernelGGL(k_msm_task_perm, dim3((pl.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, 0xffffffffu);
     HIPCHK(hipEventRecord(e->ev_a, s));
