@@ -8,7 +8,7 @@ R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-host-abi"
+COMMON="--no-cpu-baseline --no-host-abi --sustained 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py "$@" $COMMON > $O/ks.log 2>&1 || echo "ks pass failed" >> $O/ks.log
 echo "ks done" >> $O/progress.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py "$@" $COMMON --steps 2 --warmup 1 > $O/fetch.log 2>&1 || echo "fetch pass failed" >> $O/fetch.log
