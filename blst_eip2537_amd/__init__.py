@@ -10,5 +10,5 @@ There is no CPU fallback for the multiexp / pairing path: if the library is miss
 ``executor`` raises; if no HIP device is present those calls return ``memory allocation error``.
 """
 from .executor import (  # noqa: F401
-    Eip2537Error, Eip2537Executor, ERROR_STRINGS, lib, lib_path,
+    Eip2537Error, Eip2537Executor, ERROR_STRINGS, lib, lib_path, bound_hip_runtime,
 )

@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void reduce_block_to_window(const ReduceGrid &rg, con
 template <class F, class T = typename AccumField<F>::T>
 __global__ void __launch_bounds__(256, 1)      // latency-bound chain: registers over occupancy
 k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg,
-             Xyzz<F> *__restrict__ winout, Xyzz<T> *__restrict__ raw_out = nullptr) {
+             Xyzz<F> *__restrict__ winout) {
     const Xyzz<T> *__restrict__ partial = reinterpret_cast<const Xyzz<T> *>(partial_);
     int w;
     uint32_t bx;
@@ -1175,27 +1175,8 @@ k_msm_reduce4(const Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__
     __syncthreads();
     if (wave == 0 && lane < 4) {
         for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
-        if (lane == 0) {
-            if (raw_out) raw_out[blockIdx.x] = C;               // stays in the kernel's own form for k_msm_window_sum4
-            else store_canon<F, T>(&winout[blockIdx.x], C);
-        }
+        if (lane == 0) store_canon<F, T>(&winout[blockIdx.x], C);
     }
-}
-// G1, the c <= 13 plans (round 4): the per-block sums of k_msm_reduce4<Fp, FpL> stay in limb form and one more wave per window adds them
-// up -- group j of 4 lanes takes the blocks j, j + 16, ..., then the 4-level tree -- as k_msm_window_sum8c does for G2.  The host added
-// the ~232 block sums itself before: 0.35 us each, ~80 us of every call from 513 to 2^17 records.
-__global__ void __launch_bounds__(64, 1)
-k_msm_window_sum4(const Xyzz<FpL> *__restrict__ blocks, MsmPlan pl, ReduceGrid rg, Xyzz<Fp> *__restrict__ winsum) {
-    const int w = blockIdx.x, lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
-    claim_whole_simd();
-    const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
-    Xyzz<FpL> C = xyzz_inf<FpL>();
-    for (uint32_t b = (uint32_t)(lane >> 2); b < nb; b += 16u) C = add4(C, blocks[b0 + b], r, gb);      // uniform in the group
-    for (int off = 4; off < 64; off <<= 1) {
-        const Xyzz<FpL> o = shfl_from(C, (lane + off) & 63);
-        if ((lane & (2 * off - 1)) < 4) C = add4(C, o, r, gb);
-    }
-    if (lane == 0) store_canon<Fp, FpL>(&winsum[w], C);
 }
 
 // fold of lightly split G2 buckets with the 8-lane component-split addition (lanes.h)
@@ -1442,22 +1423,22 @@ static void launch_fold_big(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint3
     hipLaunchKernelGGL(k_msm_fold_big<Fp2>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff,
-                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout, Xyzz<FpL> *raw) {
-    if (limb && four) {         // block sums in limb form -> one sum per window behind the block slots of winout
-        hipLaunchKernelGGL((k_msm_reduce4<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout, raw);
-        hipLaunchKernelGGL(k_msm_window_sum4, dim3(pl.W), dim3(64), 0, s, (const Xyzz<FpL> *)raw, pl, rg, winout + red_blocks);
-    }
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout) {
+    if (limb && four) hipLaunchKernelGGL((k_msm_reduce4<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else if (limb) hipLaunchKernelGGL((k_msm_reduce1<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
-                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout, Xyzz<FpL> *) {
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     hipLaunchKernelGGL(k_msm_window_sum8c, dim3(pl.W), dim3(64), 0, s, (const Xyzz<Fp2> *)winout, pl, rg, winout + red_blocks);     // -> W window sums behind the block sums
 }
-static constexpr bool window_sums_on_device(const Fp2 *, bool, bool) { return true; }
-static constexpr bool window_sums_on_device(const Fp *, bool four, bool limb) { return four && limb; }      // the c <= 13 limb-form plans
+static constexpr bool window_sums_on_device(const Fp2 *) { return true; }
+// (round 4, measured: the same for the G1 c <= 13 plans -- block sums kept in limb form, one more wave per window, k_msm_window_sum4 --
+// is neutral: the kernel costs the device the 40-80 us it saves the host (2^16: 0.887 -> 0.872 ms, 2^12: 0.631 -> 0.639, 128 records
+// 0.423 -> 0.421; profiles/r04_size_sweep.txt).  Not kept.)
+static constexpr bool window_sums_on_device(const Fp *) { return false; }
 // Two-level reduce of a G1 c = 16 plan (k_msm_rowcol / k_msm_reduce_rc), behind the accumulate of the call's LAST record shard: the top
 // window's upper half TB is accumulated, folded and summed on stream3 beside the accumulate of everything else (TB's tasks finish long
 // before the rest: 1 / 17 of the work); the row / column launch on the critical path then is the 16 other virtual windows = exactly
@@ -1581,7 +1562,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return !v || atoi(v) != 0; }();
     const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B == kRcRows * kRcCols && pl.BT == 2u * pl.B;
     if (two_level) red_blocks = 2u * (uint32_t)(pl.W + 1);
-    const bool dev_winsum = window_sums_on_device((const F *)nullptr, four, limb_form) && !two_level;      // one sum per window comes back, not one per block
+    const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level;      // G2: one sum per window comes back, not one per block
     const size_t nwin_out = dev_winsum ? (size_t)pl.W : red_blocks;
     const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
     const uint32_t split_top = two_level ? (uint32_t)pl.W * pl.B : 0xffffffffu;      // first bucket of the top window's upper half
@@ -1643,7 +1624,6 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
-    if (dev_winsum) HIPCHK(e->rcsum.reserve((size_t)red_blocks * sizeof(Xyzz<FpL>)));      // G1: the block sums in limb form
     if (two_level) {
         HIPCHK(e->bacc.reserve((size_t)pl.NB * sizeof(Xyzz<FpL>)));
         HIPCHK(e->taskbkt.reserve((size_t)pl.max_tasks * 4));
@@ -1773,7 +1753,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             HIPCHK(hipEventRecord(e->ev_b, s));
             launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
             launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
-            launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout, reinterpret_cast<Xyzz<FpL> *>(e->rcsum.p));
+            launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
         }
     }
     HIPCHK(hipEventRecord(e->ev_stop, s));

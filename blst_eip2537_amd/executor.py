@@ -57,6 +57,7 @@ _COMBINE = {  # name -> (partial bytes, output bytes)
 }
 
 _lib = None
+_bound_runtime = "system"
 
 
 def lib_path():
@@ -68,10 +69,17 @@ def _one_hip_runtime():
     library asks for the same soname and would otherwise map /opt/rocm's copy when it is loaded first -- and whichever of the
     two runtimes opens the device second then reports "no ROCm-capable device".  So when PyTorch is installed but not imported
     yet, its copy is mapped first (without importing torch) and the loader binds the engine to it, exactly as it does when
-    `import torch` came first.  Without PyTorch the engine uses the ROCm installation's runtime."""
+    `import torch` came first.  Without PyTorch the engine uses the ROCm installation's runtime.
+    EIP2537_HIP_PRELOAD_TORCH_RUNTIME=0 turns the preload off (a process that will never import torch and wants the ROCm
+    installation's runtime); EIP2537_HIP_VERBOSE=1 logs which copy was bound."""
     import importlib.util
     import sys
+    global _bound_runtime
+    if os.environ.get("EIP2537_HIP_PRELOAD_TORCH_RUNTIME", "1") == "0":
+        _bound_runtime = "system (preload disabled)"
+        return
     if "torch" in sys.modules:
+        _bound_runtime = "torch (imported before the engine)"
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -83,8 +91,18 @@ def _one_hip_runtime():
     if os.path.exists(cand):
         try:
             ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-        except OSError:
-            pass
+            _bound_runtime = cand
+        except OSError as ex:
+            _bound_runtime = "system (mapping %s failed: %s)" % (cand, ex)
+            sys.stderr.write("[eip2537_hip] note: could not map PyTorch's HIP runtime %s (%s); the engine binds the system copy\n" % (cand, ex))
+    if os.environ.get("EIP2537_HIP_VERBOSE") == "1":
+        sys.stderr.write("[eip2537_hip] HIP runtime bound for the engine: %s\n" % _bound_runtime)
+
+
+def bound_hip_runtime():
+    """Which libamdhip64 the engine library was bound to when it was loaded (a path, or a description)."""
+    lib()
+    return _bound_runtime
 
 
 def lib():

@@ -132,3 +132,15 @@ def test_python_layer_keeps_one_hip_runtime_in_the_process():
             "print('HIPLIBS', len(libs), libs)\n" % ROOT)
     cp = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert "HIPLIBS 1 " in cp.stdout, cp.stdout[-2000:]
+
+
+def test_bound_hip_runtime_is_reported():
+    """the Python layer maps PyTorch's bundled HIP runtime before the engine (one runtime per process); which copy
+    was bound must be visible, and the preload must be something a caller can turn off."""
+    import blst_eip2537_amd as pkg
+    assert isinstance(pkg.bound_hip_runtime(), str) and pkg.bound_hip_runtime()
+    import subprocess, sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['EIP2537_HIP_PRELOAD_TORCH_RUNTIME'] = '0'\n"
+            "import blst_eip2537_amd as pkg; print(pkg.bound_hip_runtime())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
+    assert "preload disabled" in out, out
