@@ -209,6 +209,7 @@ static void slot_reset(Engine &e) {
     for (hipStream_t *s : {&e.stream, &e.stream2, &e.stream3}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     for (hipEvent_t *v : {&e.ev_start, &e.ev_stop, &e.ev_a, &e.ev_b, &e.ev_j2, &e.ev_j3, &e.ev_c}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
     for (hipEvent_t &v : e.ev_copy) { if (v) (void)hipEventDestroy(v); v = nullptr; }
+    if (e.pinned) { (void)hipHostFree(e.pinned); e.pinned = nullptr; e.pinned_cap = 0; }
     e.release_workspace();
     e.ready = false;
     e.failed = false;

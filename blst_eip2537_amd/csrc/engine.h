@@ -204,6 +204,19 @@ struct Engine {
     float last_aux_ms[2] = {0.f, 0.f};   // pairing: G1 membership kernel, line products (fold + tree2); MSM: sort stage (decode .. task order), fold + reduce
     LastPlan last_plan{};
 
+    // Pinned host memory for the few KB every call brings back (error word, window sums / Miller products): a device-to-host copy
+    // into pageable memory goes through the runtime's own staging buffer and a second host copy (round 4)
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    hipError_t need_pinned(size_t bytes) {
+        if (bytes <= pinned_cap) return hipSuccess;
+        if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_cap = 0; }
+        const size_t want = bytes < (size_t)65536 ? (size_t)65536 : bytes + bytes / 4;
+        const hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) { pinned = nullptr; return e; }
+        pinned_cap = want;
+        return hipSuccess;
+    }
     // stream2 (a pairing batch's G1 membership kernel, the copies of a staged call) and stream3 (the side chain of the two-level
     // bucket reduce: highest priority the device offers, so that its waves are placed WHILE the main stream's accumulate still has
     // blocks to dispatch) are created by the first pipeline that needs them.  Round 4: a slot that only ever serves small calls

@@ -1759,14 +1759,16 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
-    unsigned long long herr2[2] = {0, 0};       // first-error word | `heavy` flag
-    unsigned long long &herr = herr2[0];
-    std::vector<Xyzz<F>> hw(nwin_out);
+    // what comes back: first-error word | `heavy` flag | the window sums -- into the slot's pinned buffer (two direct copies, no staging)
+    HIPCHK(e->need_pinned(16 + nwin_out * sizeof(Xyzz<F>)));
+    unsigned long long *herr2 = static_cast<unsigned long long *>(e->pinned);
+    Xyzz<F> *hw = reinterpret_cast<Xyzz<F> *>(static_cast<char *>(e->pinned) + 16);
     StreamDrain drain{s};
     HIPCHK(hipMemcpyAsync(herr2, err, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hw.data(), winout + (dev_winsum ? red_blocks : 0u), nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hw, winout + (dev_winsum ? red_blocks : 0u), nwin_out * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     drain.armed = false;
+    const unsigned long long herr = herr2[0];
     staged_copy.finish();                       // (the helper has long finished: every copy event was waited for above)
     if (sort2 && (uint32_t)herr2[1] != 0u && herr == ~0ull) {
         // degenerate input (a partition above kHeavyFactor times its window's mean, e.g. all scalars equal): the partitioned sort

@@ -514,13 +514,17 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());
 
-    unsigned long long herr = 0;
-    std::vector<Fp12> L(kGroups);
+    // first-error word | the 17 group products, into the slot's pinned buffer (round 4: no staging copy on the way back)
+    HIPCHK(e->need_pinned(64 + (size_t)kGroups * sizeof(Fp12)));
+    unsigned long long *herr_p = static_cast<unsigned long long *>(e->pinned);
+    Fp12 *Lp = reinterpret_cast<Fp12 *>(static_cast<char *>(e->pinned) + 64);
     StreamDrain drain{s};
-    HIPCHK(hipMemcpyAsync(&herr, b.err, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(L.data(), step_out, (size_t)kGroups * sizeof(Fp12), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(herr_p, b.err, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(Lp, step_out, (size_t)kGroups * sizeof(Fp12), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     drain.armed = false;
+    const unsigned long long herr = *herr_p;
+    std::vector<Fp12> L(Lp, Lp + kGroups);                    // (aligned copy for the vector code below: 10 KB)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_start, e->ev_stop) == hipSuccess) e->last_kernel_ms = ms;
     if (hipEventElapsedTime(&ms, e->ev_a, e->ev_b) == hipSuccess) e->last_accum_ms = ms;

@@ -16,6 +16,8 @@ hipError_t hipGetDevice(int *d) { *d = t_dev; return hipSuccess; }
 hipError_t hipSetDevice(int d) { if (d < 0 || d >= stub_ndev()) return hipErrorInvalidDevice; t_dev = d; return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (!*p) return hipErrorOutOfMemory; g_live_allocs++; return hipSuccess; }
 hipError_t hipFree(void *p) { if (p) { free(p); g_live_allocs--; } return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
