@@ -41,6 +41,9 @@ ChipShape chip_shape(int device);
 // Order of the host -> device copies of the shards of ONE host-input call that share a device (api.hip, msm_host_abi):
 // shard s stages its records only after shard s - 1 has handed its own to the copy engine, so that the shards' pipelines
 // run one behind the other -- shard s computes while shard s + 1 copies -- instead of sharing the PCIe link.
+// (Round 4: G2 only; G1 calls are staged inside ONE pipeline, StagedCopy below.  The ordering relies on a PAGEABLE hipMemcpyAsync
+// returning only when its last byte is staged; from a pinned / registered caller buffer the copy returns at once and the shards' copies then
+// share the link -- slower, never wrong: every shard's kernels are ordered behind its own copy by its stream.)
 struct CopyGate {
     std::mutex m;
     std::condition_variable cv;

@@ -485,22 +485,28 @@ template <uint32_t STAGE>
 __global__ void __launch_bounds__(1024)
 k_sort_coarse_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t nslices, const uint32_t *__restrict__ chist,
                       const uint32_t *__restrict__ wbase, uint32_t *__restrict__ centries, const uint32_t *__restrict__ heavy) {
-    __shared__ uint32_t cnt[kMaxParts], start[kMaxParts + 1], stage[STAGE];
+    __shared__ uint32_t cnt[kMaxParts], start[kMaxParts + 1], gbase[kMaxParts], stage[STAGE];
     if (*heavy) return;
     const uint32_t slice = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
     const uint32_t parts = ((w == (uint32_t)pl.W - 1u) ? pl.BT : pl.B) >> kFineBits;
-    if (t < kMaxParts) cnt[t] = 0;
-    __syncthreads();
     const uint32_t lo = slice * pl.slice, hi = min(lo + pl.slice, pl.n);
-    for (uint32_t i = lo + t; i < hi; i += 1024u) {
-        const uint32_t v = digits[(size_t)w * pl.n + i];
-        if (v) atomicAdd(&cnt[((v >> 1) - 1u) >> kFineBits], 1u);
+    // Round 4: this slice's partition counts are not counted again (round 3: a first pass over the slice's digits with 32 768 LDS
+    // atomics) -- k_sort_coarse_scan left the exclusive prefix over (partition, slice) in chist, so a count is the difference of two
+    // neighbours of the flattened array (the last one: the window's total), and the prefix itself is where the run goes.
+    const uint32_t *crow = chist + (size_t)w * kMaxParts * nslices;
+    if (t < kMaxParts) {
+        uint32_t c = 0, g = 0;
+        if (t < parts) {
+            const uint32_t k = t * nslices + slice, E = parts * nslices;
+            g = crow[k];
+            c = (k + 1u < E ? crow[k + 1u] : wbase[w + 1] - wbase[w]) - g;
+        }
+        gbase[t] = g;
+        start[t + 1] = c;
     }
-    __syncthreads();
-    // exclusive prefix of the <= 512 counters (threads 0 .. 511, Hillis-Steele in place through `start`)
-    if (t < kMaxParts) start[t + 1] = cnt[t];
     if (t == 0) start[0] = 0;
     __syncthreads();
+    // exclusive prefix of the <= 512 counters (threads 0 .. 511, Hillis-Steele in place through `start`)
     for (uint32_t off = 1; off < kMaxParts; off <<= 1) {
         uint32_t v = 0;
         if (t < kMaxParts && t + 1 > off) v = start[t + 1 - off];
@@ -520,11 +526,10 @@ k_sort_coarse_scatter(const uint32_t *__restrict__ digits, MsmPlan pl, uint32_t 
     }
     __syncthreads();
     const uint32_t total = start[parts], base = wbase[w];
-    const uint32_t *crow = chist + (size_t)w * kMaxParts * nslices;
     for (uint32_t k = t; k < total; k += 1024u) {
         uint32_t a = 0, b = parts;                               // partition of staged position k: start[a] <= k < start[a + 1]
         while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if (start[mid] <= k) a = mid; else b = mid; }
-        centries[base + crow[(size_t)a * nslices + slice] + (k - start[a])] = stage[k];
+        centries[base + gbase[a] + (k - start[a])] = stage[k];
     }
 }
 static constexpr uint32_t kFineStage = 16384;                    // entries of a partition staged in LDS (4x the mean at 2^20)
@@ -1113,18 +1118,25 @@ template <class T> __device__ __forceinline__ Xyzz<T> small_mul4(const Xyzz<T> &
 
 // fold of lightly split buckets with 4-lane additions (G2: the one-lane chain of 1-7 Fp2 additions
 // on a few hundred lanes cost 0.19 ms at 2^16, where the 9-bit top window holds 128 records per bucket)
+// Round 4: SIXTEEN lanes per bucket -- four 4-lane groups take the partials j, j + 4 and a two-level tree joins them: at most three
+// additions in a row instead of seven (the c = 13 plans' 9-bit top window holds n / 512 records per bucket, i.e. eight 16-entry tasks
+// at 2^16 records: 45 us of that call were this chain).
 template <class F, class T = typename AccumField<F>::T>    // T: the form the accumulate kernel wrote the partials in
 __global__ void __launch_bounds__(256)
 k_msm_fold_small4(Xyzz<F> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
                   const uint32_t *__restrict__ split_counts) {
     Xyzz<T> *__restrict__ partial = reinterpret_cast<Xyzz<T> *>(partial_);
     const uint32_t n = split_counts[0];
-    const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
-    for (uint32_t h = blockIdx.x * 64u + (threadIdx.x >> 2); h < n; h += gridDim.x * 64u) {   // uniform in the group
+    const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3, grp = (lane >> 2) & 3;
+    for (uint32_t h = blockIdx.x * 16u + (threadIdx.x >> 4); h < n; h += gridDim.x * 16u) {   // uniform in the 16 lanes of a bucket
         const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
-        Xyzz<T> acc = partial[t0];
-        for (uint32_t t = t0 + 1; t < t1; t++) acc = add4(acc, partial[t], r, gb);
-        if (r == 0) partial[t0] = acc;
+        Xyzz<T> acc = xyzz_inf<T>();
+        for (uint32_t t = t0 + (uint32_t)grp; t < t1; t += 4u) acc = add4(acc, partial[t], r, gb);      // uniform in the group (<= 2 partials)
+        for (int off = 4; off < 16; off <<= 1) {
+            const Xyzz<T> o = shfl_from(acc, (lane & ~15) | ((lane + off) & 15));
+            if ((lane & (2 * off - 1)) < 4) acc = add4(acc, o, r, gb);
+        }
+        if ((lane & 15) == 0) partial[t0] = acc;
     }
 }
 
@@ -1404,11 +1416,11 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp
 }
 static void launch_fold_small(hipStream_t s, bool four, bool limb, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
     if (limb && four)
-        hipLaunchKernelGGL((k_msm_fold_small4<Fp, FpL>), dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+        hipLaunchKernelGGL((k_msm_fold_small4<Fp, FpL>), dim3(2048), dim3(256), 0, s, partial, taskoff, list, counts);
     else if (limb)
         hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
     else if (four)                                  // the plans that take the 4-lane reduce are the latency-bound ones
-        hipLaunchKernelGGL(k_msm_fold_small4<Fp>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+        hipLaunchKernelGGL(k_msm_fold_small4<Fp>, dim3(2048), dim3(256), 0, s, partial, taskoff, list, counts);
     else
         hipLaunchKernelGGL(k_msm_fold_small<Fp>, dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
 }
