@@ -299,9 +299,13 @@ def main():
     dev_index = local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: a single rank still goes through the process group, the partial / all_gather / combine step and RCCL itself
+    # (the only way to exercise the N > 1 code path with the real collective library on a one-GPU box)
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         with stdout_to_stderr():
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
@@ -340,7 +344,7 @@ def main():
         torch.cuda.synchronize()
         lpsz = {"g1msm": 192, "g2msm": 384, "pairing": 576}[lwl]
         pin_in = pin_out = dev_in = gbuf = None
-        if world > 1 and backend == "nccl":
+        if (world > 1 or force_dist) and backend == "nccl":
             pin_in = torch.empty(lpsz, dtype=torch.uint8).pin_memory()
             pin_out = torch.empty(world * lpsz, dtype=torch.uint8).pin_memory()
             dev_in = torch.empty(lpsz, dtype=torch.uint8, device="cuda")
@@ -349,7 +353,7 @@ def main():
 
         def one():
             t0 = time.perf_counter()
-            if world == 1:
+            if world == 1 and not force_dist:
                 o = X.dev_call(FULL[lwl], d_buf.data_ptr(), ln_local)
             else:
                 part = X.dev_call(PART[lwl], d_buf.data_ptr(), ln_local)
@@ -422,7 +426,7 @@ def main():
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integer arithmetic)",
             "data": "synthetic",
             "config": {"workload": "%s over 2^%d records total (%d per GPU), input resident in HBM, via C-ABI %s"
-                                   % (ORACLE[wl], log2_total, n_local, FULL[wl] if world == 1 else PART[wl] + " + RCCL all_gather + combine"),
+                                   % (ORACLE[wl], log2_total, n_local, FULL[wl] if world == 1 and not force_dist else PART[wl] + " + RCCL all_gather + combine"),
                        "records_total": n_total, "records_per_gpu": n_local, "world_size": world,
                        "parallelism": "1 GPU" if world == 1 else "record-range shards x%d, RCCL all_gather of %d-byte partials" % (world, psz)},
             "step_ms": st,                                     # rank 0's own clock around every step

@@ -43,3 +43,14 @@ def test_two_rank_line_has_weak_strong_and_split():
     assert st["g1msm"]["records_total"] == 1 << 20 and st["g1msm"]["bit_exact_vs_golden"] is True
     assert st["pairing"]["records_total"] == 1 << 12 and st["pairing"]["bit_exact_vs_golden"] is True
     assert "in_library_split" in d and "error" not in d["in_library_split"]
+
+
+def test_single_rank_through_rccl():
+    """The N > 1 step -- per-rank partial, pinned host -> device copy, RCCL all_gather_into_tensor, device -> host copy, combine -- with the
+    REAL collective library: one rank, backend nccl (= RCCL), BENCH_FORCE_DIST=1.  Several ranks cannot share the one GPU of the test box
+    under RCCL, so this is as close as a one-GPU box gets to the driver's multi-GPU run."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1")
+    env.pop("BENCH_DIST_BACKEND", None)
+    d = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-abi", "--no-secondary", "--sustained", "0"], env=env)
+    assert d["n_gpus"] == 1 and d["bit_exact_vs_golden"] is True
+    assert "all_gather" in d["config"]["workload"], d["config"]
