@@ -1480,7 +1480,10 @@ static int launch_two_level(Engine *e, const MsmPlan &pl, size_t ns, uint32_t ls
     hipLaunchKernelGGL(k_msm_accum_l, dim3(tb_blocks), dim3(256), 0, s3, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, a.ranges + 2, a.taskbkt, a.bacc, a.first_shard);
     hipLaunchKernelGGL((k_msm_fold_small<Fp, FpL>), dim3(512), dim3(256), 0, s3, a.partial, a.taskoff, a.split_small, a.totals + 2, split_g, 0xffffffffu, a.bacc);
     hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s3, a.partial, a.taskoff, a.split_big, a.totals + 2, split_g, 0xffffffffu, a.bacc);
-    rowcol(s3, unit_blocks, (uint32_t)pl.W);
+    // the side chain has the chip's other SIMDs to spare: half-length chains on twice the waves (128 instead of 64) shorten it by ~0.12 ms,
+    // which matters behind the SHORT last accumulate of a staged call (its row / column sums ran 60 us into the main launch and slowed it)
+    if (chain == 16u) hipLaunchKernelGGL(k_msm_rowcol<8u>, dim3(2u * unit_blocks), dim3(256), 0, s3, (const Xyzz<FpL> *)a.bacc, pl.B, (uint32_t)pl.W, a.rc);
+    else rowcol(s3, unit_blocks, (uint32_t)pl.W);
     HIPCHK(hipEventRecord(e->ev_j2, s3));
     hipLaunchKernelGGL(k_msm_accum_l, dim3(task_blocks), dim3(256), 0, s, a.ptl, a.entries, a.tasks, a.perm, a.totals, a.partial, a.ranges, a.taskbkt, a.bacc, a.first_shard);
     HIPCHK(hipEventRecord(e->ev_b, s));
