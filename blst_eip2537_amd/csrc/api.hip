@@ -1302,6 +1302,9 @@ __global__ void k_limb_selftest(uint64_t seed, unsigned n, unsigned long long *b
         const FpL g1 = subL<8>(A, B), g2 = subL<6>(B, A);                        // bounds 9 x 7, plus a second product: < 630
         const Fp want = sub(mul32(sub(a, b), sub(b, a)), mul32(a, b));
         if (!eq(canon_of(mul2L(g1, g2, A, negL<2>(B))), want)) atomicAdd(&bad[2], 1ull);
+        // six products, one reduction (round 4: the fused line product of the pairing fold)
+        const Fp want6 = add(add(want, add(mul32(a, a), mul32(b, sub(a, b)))), add(mul32(sub(b, a), sub(b, a)), mul32(a, b)));
+        if (!eq(canon_of(mul6L(g1, g2, A, negL<2>(B), A, A, B, g1, g2, g2, A, B)), want6)) atomicAdd(&bad[2], 1ull);
         const FpL big = selftest_grow(C, 590u);                                  // the largest operands limbk.h admits
         if (!eq(canon_of(mulL(big, D)), mul32(c, d))) atomicAdd(&bad[2], 1ull);
     }
@@ -1321,6 +1324,7 @@ __global__ void k_limb_selftest(uint64_t seed, unsigned n, unsigned long long *b
         if (!eq(mul32(mul32(sq, r390), r390), want)) atomicAdd(&bad[1], 1ull);
         if (!eq(canon_of(mulL(x, x)), sq)) atomicAdd(&bad[0], 1ull);
         if (!eq(canon_of(mul2L(x, x, x, x)), add(sq, sq))) atomicAdd(&bad[2], 1ull);
+        if (!eq(canon_of(mul6L(x, x, x, x, x, x, x, x, x, x, x, x)), add(add(add(sq, sq), add(sq, sq)), add(sq, sq)))) atomicAdd(&bad[2], 1ull);
         Fp w;
 #pragma unroll
         for (int k = 0; k < 12; k++) w.l[k] = k == 11 ? 0x0fffffffu : 0xffffffffu;      // < 2^380: inside fp_mul2_cols30's [0, 2p) range

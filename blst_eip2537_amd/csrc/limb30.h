@@ -229,6 +229,46 @@ HD FpL mul2L(const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
     }
     return fpl_take_high(col);
 }
+// a0 b0 + a1 b1 + ... + a5 b5 (three pairs of products) / 2^390 + (< p) with ONE reduction (round 4: the line products of the pairing fold
+// add three two-product sums per coefficient; 2 x 169 multiply-adds and two carry / normalise passes less than three mul2L and two additions).
+// Schedule found and checked by tools/limb_column_bounds.py (worst column 0.99999999 x 2^64 on all-ones limbs): the rows of a pair alternate as
+// in mul2L with its carry-out of columns 6..18 after row 7; BETWEEN pairs the high dwords of columns 2..22 move up; column 12 before the reduction.
+HD void mul_pair_rows(uint64_t col[27], const FpL &a, const FpL &b, const FpL &c, const FpL &d) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)a.l[j] * b.l[i];
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)c.l[j] * d.l[i];
+        if (i == 7) {
+#pragma unroll
+            for (int k = 6; k <= 18; k++) col_carry_hi(col, k);
+        }
+    }
+}
+HD FpL mul6L(const FpL &a0, const FpL &b0, const FpL &a1, const FpL &b1, const FpL &a2, const FpL &b2,
+             const FpL &a3, const FpL &b3, const FpL &a4, const FpL &b4, const FpL &a5, const FpL &b5) {
+    const uint32_t p30[13] = {K_P30};
+    uint64_t col[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) col[i] = 0;
+    mul_pair_rows(col, a0, b0, a1, b1);
+#pragma unroll
+    for (int k = 2; k <= 22; k++) col_carry_hi(col, k);
+    mul_pair_rows(col, a2, b2, a3, b3);
+#pragma unroll
+    for (int k = 2; k <= 22; k++) col_carry_hi(col, k);
+    mul_pair_rows(col, a4, b4, a5, b5);
+    col_carry_hi(col, 12);
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const uint32_t m = ((uint32_t)col[i] * K_N0_30) & kM30;
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)m * p30[j];
+        col[i + 1] += col[i] >> 30;
+    }
+    return fpl_take_high(col);
+}
 // K p - b, for b <= K p
 template <int K> HD FpL negL(const FpL &b) {
     uint32_t kp[13];

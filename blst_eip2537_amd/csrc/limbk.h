@@ -135,6 +135,17 @@ HDF LV<prod_bound((long)A * B + (long)C * D), N> mul2B(const LV<A, N> &a, const 
     EIP_EACH_LANE r.l[i] = mul2L(a.l[i], b.l[i], c.l[i], d.l[i]);
     return r;
 }
+// a0 b0 + ... + a5 b5 with one reduction (limb30.h: mul6L)
+template <int A0, int B0, int A1, int B1, int A2, int B2, int A3, int B3, int A4, int B4, int A5, int B5, int N>
+HDF LV<prod_bound((long)A0 * B0 + (long)A1 * B1 + (long)A2 * B2 + (long)A3 * B3 + (long)A4 * B4 + (long)A5 * B5), N>
+mul6B(const LV<A0, N> &a0, const LV<B0, N> &b0, const LV<A1, N> &a1, const LV<B1, N> &b1, const LV<A2, N> &a2, const LV<B2, N> &b2,
+      const LV<A3, N> &a3, const LV<B3, N> &b3, const LV<A4, N> &a4, const LV<B4, N> &b4, const LV<A5, N> &a5, const LV<B5, N> &b5) {
+    static_assert(A0 <= kMaxK && B0 <= kMaxK && A1 <= kMaxK && B1 <= kMaxK && A2 <= kMaxK && B2 <= kMaxK && A3 <= kMaxK && B3 <= kMaxK &&
+                  A4 <= kMaxK && B4 <= kMaxK && A5 <= kMaxK && B5 <= kMaxK, "product operand too large");
+    LV<prod_bound((long)A0 * B0 + (long)A1 * B1 + (long)A2 * B2 + (long)A3 * B3 + (long)A4 * B4 + (long)A5 * B5), N> r;
+    EIP_EACH_LANE r.l[i] = mul6L(a0.l[i], b0.l[i], a1.l[i], b1.l[i], a2.l[i], b2.l[i], a3.l[i], b3.l[i], a4.l[i], b4.l[i], a5.l[i], b5.l[i]);
+    return r;
+}
 // value == 0 mod p, per lane
 template <int K, int N> HDF LanePred<N> is_zero_modpB(const LV<K, N> &a) {
     LanePred<N> r;

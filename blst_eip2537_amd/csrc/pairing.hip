@@ -360,8 +360,11 @@ __device__ __forceinline__ void copy_elem(uint32_t *dst, const uint32_t *src, in
 #ifndef EIP_FOLD_WAVES
 #define EIP_FOLD_WAVES 2
 #endif
-template <bool BATCH>
-__global__ void __launch_bounds__(256, EIP_FOLD_WAVES)
+// FUSED (round 4): the six-product form of the line product (quad_fold_line<true>), one wave per SIMD (349 registers, no scratch, 3 blocks per
+// step): 0.53 -> 0.50 ms for the fold + tree of a 2^12-pair check; larger checks are throughput-bound and keep two waves per SIMD
+// (2^16 pairs: 4.71 ms against 4.79 fused; the fused form AT two waves per SIMD spills 93 registers and loses everywhere)
+template <bool BATCH, bool FUSED>
+__global__ void __launch_bounds__(256, FUSED ? 1 : EIP_FOLD_WAVES)
 k_pair_fold(const LineL *__restrict__ lines, const PairPL *__restrict__ pl, uint32_t k, const uint32_t *__restrict__ coff,
             uint32_t *__restrict__ blk_out, Fp2 *__restrict__ out_fp12, int final_out) {
     __shared__ TreeShared sh;
@@ -396,7 +399,7 @@ k_pair_fold(const LineL *__restrict__ lines, const PairPL *__restrict__ pl, uint
         asm volatile("" ::: "memory");
         const auto a0 = load_lv<LineK::A0>(rec->v[x.q][0]);
         if (!have) { f = quad_seed_line(x, a0, a1, a4); have = true; }
-        else quad_fold_line(x, f, a0, a1, a4);
+        else quad_fold_line<FUSED>(x, f, a0, a1, a4);
     }
     // quad -> element in shared memory (natural [k][q] order; the odd half is held rotated by one)
     {
@@ -495,7 +498,8 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     //  k_pair_tree2 stacks the per-block elements of a step at a pitch of kGroupPitch inside kTreeQuads slots
     static_assert((256 * EIP_FOLD_WAVES) / kSteps <= kGroupPitch, "k_pair_tree2: blocks per step exceed the group pitch");
     static_assert(kGroupSteps * kGroupPitch <= kTreeQuads, "k_pair_tree2: a group's elements exceed the block's slots");
-    const uint32_t max_blocks_per_step = std::max(1u, std::min<uint32_t>((uint32_t)kGroupPitch, (chip_shape(e->device).cus * EIP_FOLD_WAVES) / kSteps));     // 7 on 256 CUs
+    const bool fused = k <= 8192u;               // the six-product fold at one wave per SIMD (profiles/r04_pairing_fold.txt)
+    const uint32_t max_blocks_per_step = std::max(1u, std::min<uint32_t>((uint32_t)kGroupPitch, (chip_shape(e->device).cus * (fused ? 1u : (uint32_t)EIP_FOLD_WAVES)) / kSteps));     // 3 | 7 on 256 CUs
     const uint32_t tree_blocks = (uint32_t)std::min<size_t>(max_blocks_per_step, (k + kTreeQuads - 1) / kTreeQuads);
     PairBufs b{};
     int st = pairing_reserve(e, k, 64, (size_t)kSteps * tree_blocks * kElemWords * 4 + (size_t)kSteps * sizeof(Fp12), b);
@@ -506,7 +510,11 @@ int pairing_device(Engine *e, const void *d_in, size_t k, uint32_t *ml_words) {
     hipStream_t s = e->stream;
     st = pairing_front(e, reinterpret_cast<const uint32_t *>(d_in), k, nullptr, 1, b);
     if (st) return st;
-    hipLaunchKernelGGL(k_pair_fold<false>, dim3(tree_blocks, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)nullptr,
+    if (fused)
+        hipLaunchKernelGGL((k_pair_fold<false, true>), dim3(tree_blocks, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)nullptr,
+                           blk_out, step_out, 0);
+    else
+    hipLaunchKernelGGL((k_pair_fold<false, false>), dim3(tree_blocks, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)nullptr,
                        blk_out, step_out, 0);
     hipLaunchKernelGGL(k_pair_tree2, dim3(kGroups), dim3(256), 0, s, blk_out, tree_blocks, step_out);     // step_out: one Fp12 per group of steps
     HIPCHK(hipEventRecord(e->ev_c, s));
@@ -571,7 +579,7 @@ int pairing_batch_device(Engine *e, const void *d_in, const uint32_t *coff, int 
     HIPCHK(hipMemcpyAsync(d_coff, coff, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
     st = pairing_front(e, reinterpret_cast<const uint32_t *>(d_in), k, d_coff, M, b);
     if (st) return st;
-    hipLaunchKernelGGL(k_pair_fold<true>, dim3((uint32_t)M, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)d_coff,
+    hipLaunchKernelGGL((k_pair_fold<true, false>), dim3((uint32_t)M, kSteps), dim3(256), 0, s, b.lines, b.pl, (uint32_t)k, (const uint32_t *)d_coff,
                        (uint32_t *)nullptr, step_out, 1);
     HIPCHK(hipStreamWaitEvent(s, e->ev_j2, 0));
     HIPCHK(hipEventRecord(e->ev_stop, s));

@@ -175,9 +175,34 @@ template <class X, int KL, int N> HDF QuadOperand<X, KL, N> quad_operand(const X
     const auto lp = x.swap(l);
     return QuadOperand<X, KL, N>{l, x.pick_q(negB(lp), lp)};
 }
-template <class X, int K0, int K1, int K4, int N>
+// MUL6 (round 4): coefficient-major, the three two-product sums of a coefficient in ONE six-product sum with a single reduction (mul6B):
+// 3 x 1 183 multiply-adds per lane and line instead of 9 x 507, but the operand forms of all three line coefficients are alive at once --
+// 349 registers: the kernel that takes this form runs one wave per SIMD (k_pair_fold<false, true>, checks of up to 2^13 pairs).
+template <bool MUL6, class X, int K0, int K1, int K4, int N>
 HDF void quad_fold_line(const X &x, Fp12Q<N> &f, const LV<K0, N> &a0, const LV<K1, N> &a1, const LV<K4, N> &a4) {
     constexpr int K1X = 2 * K1, K4X = 2 * K4;
+    if constexpr (MUL6) {
+    const auto o0 = quad_operand(x, a0);
+    const auto o1 = quad_operand(x, widen<K1X>(a1));
+    const auto o1x = quad_operand(x, addB(a1, x.pick_q(negB(x.swap(a1)), x.swap(a1))));      // component q of (1 + u) a1
+    const auto o4 = quad_operand(x, widen<K4X>(a4));
+    const auto o4x = quad_operand(x, addB(a4, x.pick_q(negB(x.swap(a4)), x.swap(a4))));
+    const auto A01 = x.pick_c(o4x.A, o4.A), B01 = x.pick_c(o4x.B, o4.B);
+    const auto n0 = mul6B(x.template same_c<0>(f.own[0]), o0.A, x.template same_c<1>(f.own[0]), o0.B,
+                          x.template same_c<0>(f.own[2]), x.pick_c(o1x.A, o1.A), x.template same_c<1>(f.own[2]), x.pick_c(o1x.B, o1.B),
+                          x.template other_c<0>(f.own[0]), A01, x.template other_c<1>(f.own[0]), B01);
+    const auto n1 = mul6B(x.template same_c<0>(f.own[1]), o0.A, x.template same_c<1>(f.own[1]), o0.B,
+                          x.template same_c<0>(f.own[0]), o1.A, x.template same_c<1>(f.own[0]), o1.B,
+                          x.template other_c<0>(f.own[1]), A01, x.template other_c<1>(f.own[1]), B01);
+    const auto n2 = mul6B(x.template same_c<0>(f.own[2]), o0.A, x.template same_c<1>(f.own[2]), o0.B,
+                          x.template same_c<0>(f.own[1]), x.pick_c(o1.A, o1x.A), x.template same_c<1>(f.own[1]), x.pick_c(o1.B, o1x.B),
+                          x.template other_c<0>(f.own[2]), x.pick_c(o4.A, o4x.A), x.template other_c<1>(f.own[2]), x.pick_c(o4.B, o4x.B));
+    f.own[0] = widen<TreeK::F>(n0);
+    f.own[1] = widen<TreeK::F>(n1);
+    f.own[2] = widen<TreeK::F>(n2);
+    } else {
+    // term-major: the three products by a0 first, then those by a1 / xi a1, then a4 / xi a4, so that only one coefficient's operand
+    // forms are alive at a time (256 registers at two waves per SIMD)
     // own[t] a0
     const auto o0 = quad_operand(x, a0);
     const auto p0 = mul2B(x.template same_c<0>(f.own[0]), o0.A, x.template same_c<1>(f.own[0]), o0.B);
@@ -199,6 +224,7 @@ HDF void quad_fold_line(const X &x, Fp12Q<N> &f, const LV<K0, N> &a0, const LV<K
     f.own[0] = widen<TreeK::F>(n0);
     f.own[1] = widen<TreeK::F>(n1);
     f.own[2] = widen<TreeK::F>(n2);
+    }
 }
 // f = the line itself (first line of a quad): slots w^0, w^2, w^3
 template <class X, int K0, int K1, int K4, int N>

@@ -84,6 +84,26 @@ def mul2(row, first, second):
     return x.worst
 
 
+def mul6(mid, between, last):
+    """mul6L: three pairs of products; per pair the rows alternate as in mul2L with a carry-out after row 7; between pairs a wider one"""
+    x = Cols()
+    for pair in range(3):
+        for i in range(13):
+            for j in range(13):
+                x.add(i + j, M * M)
+            for j in range(13):
+                x.add(i + j, M * M)
+            if i == 7:
+                x.carry_hi(mid)
+        if pair < 2:
+            x.carry_hi(between)
+    x.carry_hi(last)
+    for i in range(13):
+        x.reduction_row(i)
+    x.take_high()
+    return x.worst
+
+
 def ranges(maxn):
     yield []
     for n in range(1, maxn + 1):
@@ -96,11 +116,12 @@ def main():
         "mulL  (carry 10..14 after row 7)": mul(7, range(10, 15)),
         "sqrL  (carry 10..14 before the reduction)": sqr(range(10, 15)),
         "mul2L (carry 6..18 after row 7 of both, 12 before the reduction)": mul2(7, range(6, 19), [12]),
+        "mul6L (6..18 after row 7 of every pair, 2..22 between pairs, 12 before the reduction)": mul6(range(6, 19), range(2, 23), [12]),
         "no carry-out at all, mulL": mul(-1, []),
     }
     ok = True
     for name, w in used.items():
-        print("%-70s worst column = %.9f x 2^64" % (name, w / LIMIT))
+        print("%-88s worst column = %.9f x 2^64" % (name, w / LIMIT))
         if "no carry" not in name:
             ok &= w < LIMIT
     if "--search" in sys.argv:

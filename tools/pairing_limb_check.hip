@@ -250,7 +250,8 @@ int main() {
             l1.l[i] = lift_big<3>((i & 1) ? a1.c1 : a1.c0);
             l4.l[i] = lift_big<3>((i & 1) ? a4.c1 : a4.c0);
         }
-        quad_fold_line(xq, fq, l0, l1, l4);
+        if (it & 1) quad_fold_line<true>(xq, fq, l0, l1, l4);          // both forms of the fold: six-product sums / nine two-product sums
+        else quad_fold_line<false>(xq, fq, l0, l1, l4);
         if (!eq(from_quad(fq), mul_by_014(f, a0, a1, a4))) bad4++;
         const Fp12Q<4> seed = quad_seed_line(xq, l0, l1, l4);
         if (!eq(from_quad(seed), mul_by_014(fp12_one(), a0, a1, a4))) bad4++;
