@@ -101,15 +101,18 @@ PAIR_MADS = {
     "k_pair_check_g1": (126 * 2 + 10 * 3 + 2) * 338 * 4,      # two 63-doubling chains x 2 rounds, 10 additions x 3, final 2
     "k_pair_fold": 68 * 4 * (9 * 507 + 3 * 338),             # 68 lines per pair
 }
+# round 4: checks of up to 2^13 pairs fold their lines with three six-product sums (one reduction each: 6 x 169 + 169) instead of nine
+# two-product sums -- fewer multiply-adds executed for the same lines (csrc/pairing_limb.h, quad_fold_line<true>)
+PAIR_FOLD_FUSED = 68 * 4 * (3 * (6 * 169 + 169) + 3 * 338)
 
 
 def pairing_valu(k, walk_ms, check_ms, fold_ms, pipeline_ms):
     """Executed v_mad_u64_u32 lane-ops of the three pairing kernels against the measured issue roof."""
     def leg(name, ms):
-        mads = PAIR_MADS[name] * k
+        mads = (PAIR_FOLD_FUSED if name == "k_pair_fold" and k <= 8192 else PAIR_MADS[name]) * k
         return {"kernel": name, "ms": ms, "lane_mads": mads, "achieved": mads / (ms * 1e-3) / 1e12 if ms > 0 else None,
                 "frac": mads / (ms * 1e-3) / MAD_PEAK if ms > 0 else None}
-    total = sum(PAIR_MADS.values()) * k
+    total = (sum(PAIR_MADS.values()) - (PAIR_MADS["k_pair_fold"] - PAIR_FOLD_FUSED if k <= 8192 else 0)) * k
     return {"bound": "valu (v_mad_u64_u32 issue)", "peak": MAD_PEAK / 1e12, "unit": "T mad lane-ops/s",
             "kernels": [leg("k_pair_lines8", walk_ms), leg("k_pair_check_g1", check_ms), leg("k_pair_fold", fold_ms)],
             "device_pipeline": {"lane_mads": total, "ms": pipeline_ms, "frac": total / (pipeline_ms * 1e-3) / MAD_PEAK if pipeline_ms > 0 else None},
