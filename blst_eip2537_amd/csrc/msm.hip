@@ -1368,18 +1368,21 @@ k_msm_rowcol(const Xyzz<FpL> *__restrict__ bacc, uint32_t B, uint32_t w0, Xyzz<F
     }
     if (sub == 0) rc[w * kRcPerWindow + (is_row ? job : kRcRows + job)] = acc;
 }
-// grid = 2 (W + 1) blocks: block 2 w sums (hi + row_weight0) Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of virtual window w; 64
-// four-lane groups per block, each a run of S entries:  sum_{e in [a, b)} (e + fw) X_e = Q + (a + offset) R  with the running sums
-// taken from the top, Q skipping its last addition when the weights start at 0.
+// grid = 3 (W + 1) blocks of 64 four-lane groups, each group a run of S = 2 entries:  block 3 w sums (hi + row_weight0) Row_hi over the
+// 128 rows, blocks 3 w + 1 / 3 w + 2 sum (lo + 1) Col_lo over the lower / upper 128 columns of virtual window w (round 4: the 256 columns
+// were one block with S = 4 -- the longest chain of the kernel; the host adds the two halves).
+//   sum_{e in [a, b)} (e + fw + weight0) X_e = Q + (a + weight0) R  with the running sums taken from the top, Q skipping its last addition
+// when the weights start at 0.
 __global__ void __launch_bounds__(256, 1)
 k_msm_reduce_rc(const Xyzz<FpL> *__restrict__ rc, int W, Xyzz<Fp> *__restrict__ winout) {
-    const int w = blockIdx.x >> 1, kind = blockIdx.x & 1;
+    const int w = blockIdx.x / 3, kind = blockIdx.x % 3;
     claim_whole_simd();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
-    const uint32_t n = kind ? kRcCols : kRcRows, fw = kind ? 1u : 0u;
-    const uint32_t weight0 = (!kind && w == W) ? kRcRows : 0u;          // the top window's upper half: rows 128 .. 255
-    const Xyzz<FpL> *ent = rc + (size_t)w * kRcPerWindow + (kind ? kRcRows : 0u);
-    const uint32_t S = n / 64u, a = (uint32_t)(threadIdx.x >> 2) * S;   // 64 groups
+    const uint32_t fw = kind ? 1u : 0u;
+    const uint32_t weight0 = kind == 2 ? 128u : (!kind && w == W) ? kRcRows : 0u;          // upper columns | the top window's upper half: rows 128 .. 255
+    const Xyzz<FpL> *ent = rc + (size_t)w * kRcPerWindow + (kind ? kRcRows + (kind == 2 ? 128u : 0u) : 0u);
+    constexpr uint32_t S = 2u;
+    const uint32_t a = (uint32_t)(threadIdx.x >> 2) * S;               // 64 groups x 2 = 128 entries
     Xyzz<FpL> R = xyzz_inf<FpL>(), Q = xyzz_inf<FpL>();
     for (uint32_t e = a + S; e > a; e--) {
         R = add4(R, ent[e - 1], r, gb);
@@ -1393,8 +1396,10 @@ k_msm_reduce_rc(const Xyzz<FpL> *__restrict__ rc, int W, Xyzz<Fp> *__restrict__ 
     __shared__ Xyzz<FpL> sm[4];
     if (lane == 0) sm[wave] = C;
     __syncthreads();
-    if (wave == 0 && lane < 4) {
-        for (int k = 1; k < 4; k++) C = add4(C, sm[k], r, 0);
+    if (wave == 0 && lane < 8) {                                       // two groups: (sm[0] + sm[1]) + (sm[2] + sm[3])
+        C = add4(sm[2 * (lane >> 2)], sm[2 * (lane >> 2) + 1], r, gb);
+        const Xyzz<FpL> o = shfl_from(C, (lane + 4) & 63);
+        if (lane < 4) C = add4(C, o, r, gb);
         if (lane == 0) store_canon<Fp, FpL>(&winout[blockIdx.x], C);
     }
 }
@@ -1576,7 +1581,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // rest, so that the launch on the critical path is exactly 1 024 waves (0.37 ms).
     static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return !v || atoi(v) != 0; }();
     const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B == kRcRows * kRcCols && pl.BT == 2u * pl.B;
-    if (two_level) red_blocks = 2u * (uint32_t)(pl.W + 1);
+    if (two_level) red_blocks = 3u * (uint32_t)(pl.W + 1);
     const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level;      // G2: one sum per window comes back, not one per block
     const size_t nwin_out = dev_winsum ? (size_t)pl.W : red_blocks;
     const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
@@ -1801,13 +1806,15 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // Horner over windows on the host (W * c doublings + a handful of additions)
     Xyzz<F> acc = xyzz_inf<F>();
     if (two_level) {
-        // window sum = 256 R_w + C_w: two half-windows of 8 bits each; the top window is its two halves added
-        hw[2 * (size_t)(pl.W - 1)] = add(hw[2 * (size_t)(pl.W - 1)], hw[2 * (size_t)pl.W]);
-        hw[2 * (size_t)(pl.W - 1) + 1] = add(hw[2 * (size_t)(pl.W - 1) + 1], hw[2 * (size_t)pl.W + 1]);
+        // window sum = 256 R_w + C_w: two half-windows of 8 bits each (C_w arrives as its lower and upper columns); the top window is its
+        // two halves added
+        for (int w = 0; w <= pl.W; w++) hw[3 * (size_t)w + 1] = add(hw[3 * (size_t)w + 1], hw[3 * (size_t)w + 2]);
+        hw[3 * (size_t)(pl.W - 1)] = add(hw[3 * (size_t)(pl.W - 1)], hw[3 * (size_t)pl.W]);
+        hw[3 * (size_t)(pl.W - 1) + 1] = add(hw[3 * (size_t)(pl.W - 1) + 1], hw[3 * (size_t)pl.W + 1]);
         for (int w = pl.W - 1; w >= 0; w--)
             for (int h = 0; h < 2; h++) {
                 for (int d = 0; d < pl.c / 2; d++) acc = dbl(acc);
-                acc = add(acc, hw[2 * w + h]);
+                acc = add(acc, hw[3 * w + h]);
             }
     } else if (dev_winsum) {
         for (int w = pl.W - 1; w >= 0; w--) {
