@@ -1305,6 +1305,8 @@ __global__ void k_limb_selftest(uint64_t seed, unsigned n, unsigned long long *b
         // six products, one reduction (round 4: the fused line product of the pairing fold)
         const Fp want6 = add(add(want, add(mul32(a, a), mul32(b, sub(a, b)))), add(mul32(sub(b, a), sub(b, a)), mul32(a, b)));
         if (!eq(canon_of(mul6L(g1, g2, A, negL<2>(B), A, A, B, g1, g2, g2, A, B)), want6)) atomicAdd(&bad[2], 1ull);
+        // four products, one reduction (the G2 accumulate's Y3 per component)
+        if (!eq(canon_of(mul4L(g1, g2, A, negL<2>(B), A, A, B, g1)), add(want, add(mul32(a, a), mul32(b, sub(a, b)))))) atomicAdd(&bad[2], 1ull);
         const FpL big = selftest_grow(C, 590u);                                  // the largest operands limbk.h admits
         if (!eq(canon_of(mulL(big, D)), mul32(c, d))) atomicAdd(&bad[2], 1ull);
     }
@@ -1325,6 +1327,7 @@ __global__ void k_limb_selftest(uint64_t seed, unsigned n, unsigned long long *b
         if (!eq(canon_of(mulL(x, x)), sq)) atomicAdd(&bad[0], 1ull);
         if (!eq(canon_of(mul2L(x, x, x, x)), add(sq, sq))) atomicAdd(&bad[2], 1ull);
         if (!eq(canon_of(mul6L(x, x, x, x, x, x, x, x, x, x, x, x)), add(add(add(sq, sq), add(sq, sq)), add(sq, sq)))) atomicAdd(&bad[2], 1ull);
+        if (!eq(canon_of(mul4L(x, x, x, x, x, x, x, x)), add(add(sq, sq), add(sq, sq)))) atomicAdd(&bad[2], 1ull);
         Fp w;
 #pragma unroll
         for (int k = 0; k < 12; k++) w.l[k] = k == 11 ? 0x0fffffffu : 0xffffffffu;      // < 2^380: inside fp_mul2_cols30's [0, 2p) range

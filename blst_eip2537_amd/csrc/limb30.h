@@ -269,6 +269,28 @@ HD FpL mul6L(const FpL &a0, const FpL &b0, const FpL &a1, const FpL &b1, const F
     }
     return fpl_take_high(col);
 }
+// a0 b0 + a1 b1 + a2 b2 + a3 b3 (two pairs) / 2^390 + (< p) with ONE reduction: the first two pairs of mul6L's schedule, so every column
+// stays below what tools/limb_column_bounds.py found for the six-product sum (all terms are non-negative).  The G2 accumulate's
+// Y3 = R (Q - X3) - Y1 PPP over Fp2 is one of these per component (msm.hip, k_msm_accum2c_l).
+HD FpL mul4L(const FpL &a0, const FpL &b0, const FpL &a1, const FpL &b1, const FpL &a2, const FpL &b2, const FpL &a3, const FpL &b3) {
+    const uint32_t p30[13] = {K_P30};
+    uint64_t col[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) col[i] = 0;
+    mul_pair_rows(col, a0, b0, a1, b1);
+#pragma unroll
+    for (int k = 2; k <= 22; k++) col_carry_hi(col, k);
+    mul_pair_rows(col, a2, b2, a3, b3);
+    col_carry_hi(col, 12);
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const uint32_t m = ((uint32_t)col[i] * K_N0_30) & kM30;
+#pragma unroll
+        for (int j = 0; j < 13; j++) col[i + j] += (uint64_t)m * p30[j];
+        col[i + 1] += col[i] >> 30;
+    }
+    return fpl_take_high(col);
+}
 // K p - b, for b <= K p
 template <int K> HD FpL negL(const FpL &b) {
     uint32_t kp[13];

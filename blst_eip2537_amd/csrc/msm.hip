@@ -174,6 +174,20 @@ __device__ __forceinline__ FpL load_limbs(const uint32_t *src) {
     }
     return v;
 }
+// Point record of the limb-form G2 accumulate (k_msm_accum2c_l): per Fp2 COMPONENT q the limbs of x_q R', y_q R' and -y_q R' -- the lane
+// that holds component q reads c[q] for its own operands and c[q ^ 1] for its partner's (no lane exchange for the loaded point).
+struct PtL2 { uint32_t c[2][3][14]; };
+__device__ __forceinline__ void store_limb_record(void *, uint32_t, const Aff<Fp> &) {}
+__device__ __forceinline__ void store_limb_record(void *recs, uint32_t i, const Aff<Fp2> &a) {
+    PtL2 *r = reinterpret_cast<PtL2 *>(recs) + i;
+    const FpL y0 = fpl_from_mont(a.y.c0), y1 = fpl_from_mont(a.y.c1);
+    store_limbs(r->c[0][0], fpl_from_mont(a.x.c0));
+    store_limbs(r->c[0][1], y0);
+    store_limbs(r->c[0][2], negL<1>(y0));
+    store_limbs(r->c[1][0], fpl_from_mont(a.x.c1));
+    store_limbs(r->c[1][1], y1);
+    store_limbs(r->c[1][2], negL<1>(y1));
+}
 // Wire -> limb record in one go (G1, limb-form plans): the coordinates go from raw words straight to x R', y R'
 // (one product of the R world each, by R R' mod p) and the curve equation is checked on limbs -- 2 products
 // + 2 limb squarings + 1 limb product instead of the 7 products of decode_point() followed by a conversion.
@@ -218,8 +232,9 @@ __device__ __forceinline__ int decode_point_limbs(PtL *dst, const uint32_t *w, b
 
 template <class F>
 __global__ void __launch_bounds__(256)
-k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts, PtL *__restrict__ ptl,
+k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ pts, void *__restrict__ limb_recs,
              uint32_t *__restrict__ digits, unsigned long long *err, uint32_t err_base) {
+    PtL *ptl = std::is_same<F, Fp>::value ? reinterpret_cast<PtL *>(limb_recs) : nullptr;     // G1: PtL; G2: PtL2 (store_limb_record)
     // pl.n records at `in`: a whole call, or one record shard of a staged call -- err_base is then the shard's first record, so
     // that the error word still orders bad records by their index in the CALL
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -234,7 +249,8 @@ k_msm_decode(const uint32_t *__restrict__ in, MsmPlan pl, Aff<F> *__restrict__ p
             Aff<F> a;
             st = decode_point_inl<F>(a, w);
             if (st == E_SUCCESS && !is_inf(a)) {
-                pts[i] = a;
+                if (limb_recs) store_limb_record(limb_recs, i, a);
+                else pts[i] = a;
                 live = true;
             }
         }
@@ -920,6 +936,87 @@ template <int CTRL> __device__ __forceinline__ FpL quad_perm(const FpL &a) {
 }
 template <int J> __device__ __forceinline__ FpL quad_from(const FpL &a) { return quad_perm<J * 0x55>(a); }
 
+// ---- G2 accumulate in limb form: 2 lanes per task, lane q holds COMPONENT q of everything -----------------
+// k_msm_accum2c computes in FpI (12 x 32-bit words re-sliced into 30-bit limbs around every product, conditional corrections in every
+// linear step) and has lane r multiply PRODUCT r of a round whole, which costs three exchanges and a dozen selects per round.  Here values
+// stay in limbs (limb30.h: no re-slicing, differences as a + K p - b) and lane q computes component q of EVERY product:
+//     (u v)_0 = u0 v0 - u1 v1        (u v)_1 = u0 v1 + u1 v0          one two-product sum with one reduction each (mul2L)
+//     (u^2)_0 = (u0 + u1)(u0 - u1)   (u^2)_1 = 2 u0 u1                one product each
+//     (a b - c d)_q                                                   one four-product sum (mul4L): Y3 = R (Q - X3) - Y1 PPP
+// so a lane needs its partner's component of every operand (one 13-limb exchange with lane ^ 1 per operand, 9 per entry; the loaded
+// point's are read from memory) and two selects per product.  4 563 multiply-adds per entry and lane against 5 070.
+// Bounds as in madd_l (units of p): x < 8, y < 4, zz, zzz < 2 between entries; P < 10, R < 6; every product sum < 630.
+struct C2 { FpL m, o; };                            // my component, my partner's
+__device__ __forceinline__ C2 with_partner(const FpL &m) { return C2{m, quad_perm<kDppSwap>(m)}; }
+// component q of u v;  KV bounds v
+template <int KV> __device__ __forceinline__ FpL mul_c(const C2 &u, const C2 &v, int q) {
+    return mul2L(u.m, sel2(q, v.m, v.o), u.o, sel2(q, negL<KV>(v.o), v.m));
+}
+// component q of u^2;  KU bounds u
+template <int KU> __device__ __forceinline__ FpL sqr_c(const C2 &u, int q) {
+    return mulL(addL(u.m, sel2(q, u.o, u.m)), sel2(q, subL<KU>(u.m, u.o), u.o));
+}
+// component q of a b - c d;  KB, KD bound b and d
+template <int KB, int KD> __device__ __forceinline__ FpL mul_sub_c(const C2 &a, const C2 &b, const C2 &c, const C2 &d, int q) {
+    const FpL nbo = negL<KB>(b.o), ndm = negL<KD>(d.m), ndo = negL<KD>(d.o);
+    return mul4L(a.m, sel2(q, b.m, b.o), a.o, sel2(q, nbo, b.m), c.m, sel2(q, ndm, ndo), c.o, sel2(q, d.o, ndm));
+}
+struct AccL2 { FpL x, y, zz, zzz; };                // one component of an XYZZ point over Fp2
+// 2Q for affine Q != infinity (mdbl-2008-s-1); rare
+__device__ __forceinline__ AccL2 dbl_affine2c_l(const C2 &qx, const C2 &qy, int q) {
+    const C2 U = with_partner(addL(qy.m, qy.m));                             // < 4
+    const C2 V = with_partner(sqr_c<4>(U, q));                                // < 2
+    const FpL W = mul_c<2>(U, V, q), S = mul_c<2>(qx, V, q), XX = sqr_c<2>(qx, q);
+    const C2 M = with_partner(dbl_addL(XX, XX));                             // 3 x^2 < 6
+    const FpL X3 = sub2L<4>(sqr_c<6>(M, q), S);                               // < 6
+    const FpL Y3 = mul_sub_c<8, 2>(M, with_partner(subL<6>(S, X3)), with_partner(W), qy, q);     // M (S - X3) - W y: < 2
+    return AccL2{X3, Y3, V.m, W};
+}
+__global__ void __launch_bounds__(256)
+k_msm_accum2c_l(const PtL2 *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
+                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp2> *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, q = lane & 1;
+    const uint32_t slot = blockIdx.x * 128u + (threadIdx.x >> 1);
+    if (slot >= totals[1]) return;                             // uniform in the pair
+    const uint32_t t = perm[slot];
+    const Task tk = tasks[t];
+    AccL2 acc;
+    bool inf = true;                                           // uniform in the pair
+    for (uint32_t e = 0; e < tk.len; e++) {
+        const uint32_t ent = entries[tk.start + e];
+        const PtL2 *p = &pts[ent >> 1];
+        const int ys = (ent & 1u) ? 2 : 1;
+        const C2 qx{load_limbs(p->c[q][0]), load_limbs(p->c[q ^ 1][0])}, qy{load_limbs(p->c[q][ys]), load_limbs(p->c[q ^ 1][ys])};
+        if (inf) {
+            const FpL one_q = q ? fpl_zero() : fpl_one();
+            acc = AccL2{qx.m, qy.m, one_q, one_q};
+            inf = false;
+            continue;
+        }
+        const C2 zz = with_partner(acc.zz), zzz = with_partner(acc.zzz);
+        const FpL P = subL<8>(mul_c<2>(qx, zz, q), acc.x);                     // < 10
+        const FpL R = subL<4>(mul_c<2>(qy, zzz, q), acc.y);                    // < 6
+        if (both2(is_zero_modp(P, 10), lane)) {
+            if (both2(is_zero_modp(R, 6), lane)) acc = dbl_affine2c_l(qx, qy, q);
+            else inf = true;
+            continue;
+        }
+        const C2 cP = with_partner(P), cR = with_partner(R);
+        const C2 PP = with_partner(sqr_c<10>(cP, q));
+        const FpL RR = sqr_c<6>(cR, q);
+        const C2 PPP = with_partner(mul_c<2>(cP, PP, q));
+        const FpL Q = mul_c<2>(with_partner(acc.x), PP, q);
+        const FpL X3 = sub2L<4>(subL<2>(RR, PPP.m), Q);                        // R^2 - PPP - 2 Q + 6 p < 8
+        acc.y = mul_sub_c<10, 2>(cR, with_partner(subL<8>(Q, X3)), with_partner(acc.y), PPP, q);     // 2 x 6 x 10 + 2 x 4 x 2 < 630; < 2
+        acc.zz = mul_c<2>(zz, PP, q);
+        acc.zzz = mul_c<2>(zzz, PPP, q);
+        acc.x = X3;
+    }
+    // back to the [0, 2p) words the fold and reduce kernels of G2 compute in
+    const Xyzz<FpI> out = inf ? xyzz_inf<FpI>() : Xyzz<FpI>{to_fpi(acc.x), to_fpi(acc.y), to_fpi(acc.zz), to_fpi(acc.zzz)};
+    store_component(&partial[t], out, q);
+}
+
 // ---- limb-form versions of the lane-split point operations (chain-bound G1 plans, c <= 13) -----------
 // Same rounds as add4 / dbl4 / madd2 below and above; values are FpL with the standard bounds of limb30.h
 // (x < 8, y < 4, zz, zzz < 2 in units of p), differences are a + K p - b.
@@ -1404,8 +1501,79 @@ k_msm_reduce_rc(const Xyzz<FpL> *__restrict__ rc, int W, Xyzz<Fp> *__restrict__ 
     }
 }
 
-static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const PtL *ptl, const uint32_t *entries,
+// ---- two-level bucket reduce of the chain-bound G1 plans (c = 13: 8 193 .. 2^17 records; round 4) -----------------------------
+// k_msm_reduce4 is ONE chain per 4-lane group -- 2 S running-sum additions, an offset multiple of ~15 addition-times, a 7-level tree: 0.31 ms of
+// a 0.88 ms call at 2^16 records -- and leaves ~230 block sums for the host to add (80 us).  The split of the large plans works here too: a
+// window's B = 4 096 buckets are 64 rows x 64 columns (bucket value v = 64 hi + lo + 1; the 9-bit top window: 8 x 64), so
+//     sum_v v B_v = 64 sum_hi hi Row_hi + sum_lo (lo + 1) Col_lo.
+// k_msm_rowcol_p: plain row / column sums, one lane per chain of kRcpChain buckets (general XYZZ additions in limb form), then a tree over the
+// job's 16 (top window's columns: 2) lanes -- 3 + 4 additions deep on 612 waves; k_msm_reduce_rc_p: the weighted sums over 64 (8) entries per
+// (window, kind), one entry per 4-lane group.  The host's Horner takes R_w and C_w as a 7-bit and a 6-bit half-window: 40 points instead of 230.
+struct RcpGeom { uint32_t B, BT, logC, W; };
+static constexpr uint32_t kRcpChain = 4;
+__global__ void __launch_bounds__(256)
+k_msm_rowcol_p(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, RcpGeom g, Xyzz<FpL> *__restrict__ rc) {
+    const Xyzz<FpL> *__restrict__ partial = reinterpret_cast<const Xyzz<FpL> *>(partial_);
+    const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rt = g.BT >> g.logC;
+    const uint32_t lanes_w = 2u * g.B / kRcpChain, lanes_t = 2u * g.BT / kRcpChain, main_total = (g.W - 1u) * lanes_w;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t w, local, Rw, nb;
+    if (t < main_total) { w = t / lanes_w; local = t % lanes_w; Rw = R; nb = g.B; }
+    else { local = t - main_total; if (local >= lanes_t) return; w = g.W - 1u; Rw = Rt; nb = g.BT; }      // uniform in the wave (multiples of 64)
+    const uint32_t row_lanes = nb / kRcpChain;
+    const bool is_row = local < row_lanes;                             // uniform in the wave
+    const uint32_t lj = is_row ? C / kRcpChain : Rw / kRcpChain;       // lanes per job
+    const uint32_t l2 = is_row ? local : local - row_lanes, job = l2 / lj, sub = l2 % lj;
+    // row job: buckets C job + (sub + i lj);   column job: buckets C (sub + i lj) + job
+    const uint32_t first = w * g.B + (is_row ? job * C + sub : sub * C + job);
+    const uint32_t step = is_row ? lj : lj * C;
+    auto fetch = [&](uint32_t i) {
+        const uint32_t b = first + i * step, t0 = taskoff[b], t1 = taskoff[b + 1];
+        return t1 > t0 ? partial[t0] : xyzz_inf<FpL>();                // multi-task buckets were folded into slot t0
+    };
+    Xyzz<FpL> acc = fetch(0), nxt = fetch(1);
+#pragma unroll 1
+    for (uint32_t i = 1; i < kRcpChain; i++) {
+        const Xyzz<FpL> cur = nxt;
+        if (i + 1 < kRcpChain) nxt = fetch(i + 1);                      // in flight during the addition below
+        acc = add(acc, cur);
+    }
+    const int lane = threadIdx.x & 63;
+    for (uint32_t off = lj >> 1; off >= 1; off >>= 1) {                 // the job's lanes are one aligned run of the wave
+        const Xyzz<FpL> o = shfl_from(acc, (lane + (int)off) & 63);
+        if (sub < off) acc = add(acc, o);
+    }
+    if (sub == 0) rc[w * (R + C) + (is_row ? job : Rw + job)] = acc;
+}
+// grid = 2 W blocks: block 2 w sums hi Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of window w; 64 four-lane groups, one entry each
+__global__ void __launch_bounds__(256, 1)
+k_msm_reduce_rc_p(const Xyzz<FpL> *__restrict__ rc, RcpGeom g, Xyzz<Fp> *__restrict__ winout) {
+    const uint32_t w = blockIdx.x >> 1, kind = blockIdx.x & 1u;
+    claim_whole_simd();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, gb = lane & ~3;
+    const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rw = w == g.W - 1u ? g.BT >> g.logC : R;
+    const uint32_t n = kind ? C : Rw, e = (uint32_t)(threadIdx.x >> 2);       // entry of this group (n <= 64)
+    const Xyzz<FpL> *ent = rc + (size_t)w * (R + C) + (kind ? Rw : 0u);
+    Xyzz<FpL> Cs = xyzz_inf<FpL>();
+    if (e < n) Cs = small_mul4(ent[e], e + kind, r, gb);               // uniform in the group; weight hi | lo + 1
+    for (int off = 4; off < 64; off <<= 1) {
+        Xyzz<FpL> o = shfl_from(Cs, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 4) Cs = add4(Cs, o, r, gb);
+    }
+    __shared__ Xyzz<FpL> sm[4];
+    if (lane == 0) sm[wave] = Cs;
+    __syncthreads();
+    if (wave == 0 && lane < 8) {
+        Cs = add4(sm[2 * (lane >> 2)], sm[2 * (lane >> 2) + 1], r, gb);
+        const Xyzz<FpL> o = shfl_from(Cs, (lane + 4) & 63);
+        if (lane < 4) Cs = add4(Cs, o, r, gb);
+        if (lane == 0) store_canon<Fp, FpL>(&winout[blockIdx.x], Cs);
+    }
+}
+
+static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const void *limb_recs, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
+    const PtL *ptl = reinterpret_cast<const PtL *>(limb_recs);
     if (chain_bound && ptl)
         hipLaunchKernelGGL(k_msm_accum2_l, dim3(task_blocks * 2u), dim3(256), 0, s, ptl, entries, tasks, perm, totals, partial);
     else if (chain_bound)
@@ -1415,9 +1583,12 @@ static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, 
     else
         hipLaunchKernelGGL(k_msm_accum<Fp>, dim3(task_blocks), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
-static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp2> *pts, const PtL *, const uint32_t *entries,
+static void launch_accum(hipStream_t s, uint32_t task_blocks, bool, const Aff<Fp2> *pts, const void *limb_recs, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp2> *partial) {
-    hipLaunchKernelGGL(k_msm_accum2c, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
+    if (limb_recs)
+        hipLaunchKernelGGL(k_msm_accum2c_l, dim3(task_blocks * 2u), dim3(256), 0, s, (const PtL2 *)limb_recs, entries, tasks, perm, totals, partial);
+    else
+        hipLaunchKernelGGL(k_msm_accum2c, dim3(task_blocks * 2u), dim3(256), 0, s, pts, entries, tasks, perm, totals, partial);
 }
 static void launch_fold_small(hipStream_t s, bool four, bool limb, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
     if (limb && four)
@@ -1440,14 +1611,20 @@ static void launch_fold_big(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint3
     hipLaunchKernelGGL(k_msm_fold_big<Fp2>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff,
-                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout) {
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout, const RcpGeom *rcp, Xyzz<FpL> *rc) {
+    if (rcp) {                  // c = 13: row / column sums, then the weighted sums (two launches; red_blocks = 2 W)
+        const uint32_t lanes = (rcp->W - 1u) * (2u * rcp->B / kRcpChain) + 2u * rcp->BT / kRcpChain;
+        hipLaunchKernelGGL(k_msm_rowcol_p, dim3((lanes + 255u) / 256u), dim3(256), 0, s, partial, taskoff, *rcp, rc);
+        hipLaunchKernelGGL(k_msm_reduce_rc_p, dim3(red_blocks), dim3(256), 0, s, (const Xyzz<FpL> *)rc, *rcp, winout);
+        return;
+    }
     if (limb && four) hipLaunchKernelGGL((k_msm_reduce4<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else if (limb) hipLaunchKernelGGL((k_msm_reduce1<Fp, FpL>), dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
-                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout) {
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout, const RcpGeom *, Xyzz<FpL> *) {
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     hipLaunchKernelGGL(k_msm_window_sum8c, dim3(pl.W), dim3(64), 0, s, (const Xyzz<Fp2> *)winout, pl, rg, winout + red_blocks);     // -> W window sums behind the block sums
 }
@@ -1582,6 +1759,12 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     static const bool env_rc = [] { const char *v = getenv("EIP2537_REDUCE_RC"); return !v || atoi(v) != 0; }();
     const bool two_level = limb_form && env_rc && !four && pl.c == 16 && pl.B == kRcRows * kRcCols && pl.BT == 2u * pl.B;
     if (two_level) red_blocks = 3u * (uint32_t)(pl.W + 1);
+    // G1, c = 13 (8 193 .. 2^17 records): the same split for the chain-bound plans (k_msm_rowcol_p / k_msm_reduce_rc_p); EIP2537_REDUCE_RCP=0:
+    // the 4-lane running-sum chain k_msm_reduce4
+    static const bool env_rcp = [] { const char *v = getenv("EIP2537_REDUCE_RCP"); return !v || atoi(v) != 0; }();
+    const RcpGeom rcp{pl.B, pl.BT, 6u, (uint32_t)pl.W};
+    const bool two_level_p = !two_level && limb_form && four && env_rcp && !ReduceCfg<F>::kFourLane && pl.c == 13 && pl.B == 4096u && pl.BT == 512u;
+    if (two_level_p) red_blocks = 2u * (uint32_t)pl.W;
     const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level;      // G2: one sum per window comes back, not one per block
     const size_t nwin_out = dev_winsum ? (size_t)pl.W : red_blocks;
     const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
@@ -1616,7 +1799,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     pl.L = 1u << shift_for(ns_max);
     pl.max_tasks = max_tasks;
-    HIPCHK(e->pts.reserve((size_t)ns_max * (limb_form ? sizeof(PtL) : sizeof(Aff<F>))));
+    // G2: the accumulate in limb form too (k_msm_accum2c_l; fold and reduce stay in FpI words); EIP2537_G2_LIMB=0: k_msm_accum2c
+    static const bool env_g2limb = [] { const char *v = getenv("EIP2537_G2_LIMB"); return !v || atoi(v) != 0; }();
+    const bool g2_limb = ReduceCfg<F>::kFourLane && env_g2limb;
+    HIPCHK(e->pts.reserve((size_t)ns_max * (limb_form ? sizeof(PtL) : g2_limb ? sizeof(PtL2) : sizeof(Aff<F>))));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
@@ -1644,6 +1830,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
+    if (two_level_p) HIPCHK(e->rcsum.reserve((size_t)pl.W * 128u * sizeof(Xyzz<FpL>)));      // per window: 64 row + 64 column sums
     if (two_level) {
         HIPCHK(e->bacc.reserve((size_t)pl.NB * sizeof(Xyzz<FpL>)));
         HIPCHK(e->taskbkt.reserve((size_t)pl.max_tasks * 4));
@@ -1678,11 +1865,12 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     uint32_t *taskbkt = two_level ? reinterpret_cast<uint32_t *>(e->taskbkt.p) : nullptr;
     Xyzz<FpL> *bacc = two_level ? reinterpret_cast<Xyzz<FpL> *>(e->bacc.p) : nullptr;
     PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
+    void *limb_recs = (limb_form || g2_limb) ? e->pts.p : nullptr;          // PtL (G1) | PtL2 (G2) records in place of the affine points
 
     {
         const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
         LastPlan lp{};
-        if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, "k_msm_accum2c");        // G2: split by component
+        if (ReduceCfg<F>::kFourLane) snprintf(lp.kernel, sizeof lp.kernel, g2_limb ? "k_msm_accum2c_l" : "k_msm_accum2c");        // G2: split by component
         else if (limb_form) snprintf(lp.kernel, sizeof lp.kernel, two_lane ? "k_msm_accum2_l" : "k_msm_accum_l");
         else snprintf(lp.kernel, sizeof lp.kernel, "%s<%s>", two_lane ? "k_msm_accum2" : "k_msm_accum", ReduceCfg<F>::kName);
         lp.c = pl.c; lp.windows = pl.W; lp.lanes = two_lane ? 2 : 1; lp.units = (uint32_t)n; lp.buckets = pl.NB; lp.shards = K;
@@ -1729,7 +1917,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             HIPCHK(ce);
         }
         // totals: [0] entries [1] tasks [2] lightly split [3] heavily split buckets -- written / cleared by k_msm_scan_sums' last block
-        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, ps, pts, ptl, digits, err, r0);
+        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, ps, pts, limb_recs, digits, err, r0);
         if (!sort2 && small_lds) hipLaunchKernelGGL(k_msm_hist<4096u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
         else if (!sort2) hipLaunchKernelGGL(k_msm_hist<kLdsWords>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
         const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
@@ -1769,11 +1957,11 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             if (st2) return st2;
         } else {
             // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
-            launch_accum(s, task_blocks, pl.c <= 13, pts, ptl, entries, tasks, perm, totals, partial);
+            launch_accum(s, task_blocks, pl.c <= 13, pts, limb_recs, entries, tasks, perm, totals, partial);
             HIPCHK(hipEventRecord(e->ev_b, s));
             launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
             launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
-            launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout);
+            launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout, two_level_p ? &rcp : nullptr, reinterpret_cast<Xyzz<FpL> *>(e->rcsum.p));
         }
     }
     HIPCHK(hipEventRecord(e->ev_stop, s));
@@ -1816,6 +2004,14 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
                 for (int d = 0; d < pl.c / 2; d++) acc = dbl(acc);
                 acc = add(acc, hw[3 * w + h]);
             }
+    } else if (two_level_p) {
+        // window sum = 64 R_w + C_w: a 7-bit and a 6-bit half-window
+        for (int w = pl.W - 1; w >= 0; w--) {
+            for (int d = 0; d < pl.c - (int)rcp.logC; d++) acc = dbl(acc);
+            acc = add(acc, hw[2 * (size_t)w]);
+            for (int d = 0; d < (int)rcp.logC; d++) acc = dbl(acc);
+            acc = add(acc, hw[2 * (size_t)w + 1]);
+        }
     } else if (dev_winsum) {
         for (int w = pl.W - 1; w >= 0; w--) {
             for (int d = 0; d < pl.c; d++) acc = dbl(acc);

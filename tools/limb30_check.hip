@@ -37,6 +37,8 @@ int main() {
         // six products, one reduction (round 4: the fused line product of the pairing fold)
         if (!eq(canon_of(mul6L(g1, g2, A, negL<2>(B), A, A, B, g1, g2, g2, A, B)),
                 add(add(sub(mul(sub(a, b), sub(b, a)), mul(a, b)), add(mul(a, a), mul(b, sub(a, b)))), add(mul(sub(b, a), sub(b, a)), mul(a, b))))) bad++;
+        if (!eq(canon_of(mul4L(g1, g2, A, negL<2>(B), A, A, B, g1)),
+                add(sub(mul(sub(a, b), sub(b, a)), mul(a, b)), add(mul(a, a), mul(b, sub(a, b)))))) bad++;
         if (is_zero_modp(g1, 10) != eq(a, b)) bad++;
         if (!is_zero_modp(subL<8>(A, A), 10) || !is_zero_modp(subL<3>(A, A), 4)) bad++;
     }
@@ -64,7 +66,7 @@ int main() {
         const Fp sq = canon_of(sqrL(x));
         const Fp sq6 = add(add(add(sq, sq), add(sq, sq)), add(sq, sq));
         const bool ok = eq(got, mul(v, v)) && eq(canon_of(mulL(x, x)), sq) && eq(canon_of(mul2L(x, x, x, x)), add(sq, sq)) &&
-                        eq(canon_of(mul6L(x, x, x, x, x, x, x, x, x, x, x, x)), sq6);
+                        eq(canon_of(mul6L(x, x, x, x, x, x, x, x, x, x, x, x)), sq6) && eq(canon_of(mul4L(x, x, x, x, x, x, x, x)), add(add(sq, sq), add(sq, sq)));
         printf("extreme limbs: %s\n", ok ? "ok" : "MISMATCH");
         if (!ok) bad++;
     }

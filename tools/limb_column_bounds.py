@@ -84,10 +84,10 @@ def mul2(row, first, second):
     return x.worst
 
 
-def mul6(mid, between, last):
-    """mul6L: three pairs of products; per pair the rows alternate as in mul2L with a carry-out after row 7; between pairs a wider one"""
+def mul6(mid, between, last, pairs=3):
+    """mul6L (mul4L: pairs = 2): pairs of products; per pair the rows alternate as in mul2L with a carry-out after row 7; between pairs a wider one"""
     x = Cols()
-    for pair in range(3):
+    for pair in range(pairs):
         for i in range(13):
             for j in range(13):
                 x.add(i + j, M * M)
@@ -95,7 +95,7 @@ def mul6(mid, between, last):
                 x.add(i + j, M * M)
             if i == 7:
                 x.carry_hi(mid)
-        if pair < 2:
+        if pair < pairs - 1:
             x.carry_hi(between)
     x.carry_hi(last)
     for i in range(13):
@@ -117,6 +117,7 @@ def main():
         "sqrL  (carry 10..14 before the reduction)": sqr(range(10, 15)),
         "mul2L (carry 6..18 after row 7 of both, 12 before the reduction)": mul2(7, range(6, 19), [12]),
         "mul6L (6..18 after row 7 of every pair, 2..22 between pairs, 12 before the reduction)": mul6(range(6, 19), range(2, 23), [12]),
+        "mul4L (the first two pairs of mul6L's schedule)": mul6(range(6, 19), range(2, 23), [12], pairs=2),
         "no carry-out at all, mulL": mul(-1, []),
     }
     ok = True
