@@ -972,7 +972,16 @@ __device__ __forceinline__ AccL2 dbl_affine2c_l(const C2 &qx, const C2 &qy, int 
     const FpL Y3 = mul_sub_c<8, 2>(M, with_partner(subL<6>(S, X3)), with_partner(W), qy, q);     // M (S - X3) - W y: < 2
     return AccL2{X3, Y3, V.m, W};
 }
-__global__ void __launch_bounds__(256)
+// Register budget (measured, profiles/r04_g2_limb_accum.txt): with every partner copy kept only as long as its products the kernel
+// needs 236 VGPRs -> two waves per SIMD, 2^18 records 2.49 ms; the first form (276 VGPRs, one wave) 2.65; one wave with the next
+// entry's point prefetched 2.75; k_msm_accum2c 2.95.
+struct PtC2 { C2 x, y; };
+__device__ __forceinline__ PtC2 load_pt2(const PtL2 *__restrict__ pts, uint32_t ent, int q) {
+    const PtL2 *p = &pts[ent >> 1];
+    const int ys = (ent & 1u) ? 2 : 1;
+    return PtC2{C2{load_limbs(p->c[q][0]), load_limbs(p->c[q ^ 1][0])}, C2{load_limbs(p->c[q][ys]), load_limbs(p->c[q ^ 1][ys])}};
+}
+__global__ void __launch_bounds__(256, 2)
 k_msm_accum2c_l(const PtL2 *__restrict__ pts, const uint32_t *__restrict__ entries, const Task *__restrict__ tasks,
                 const uint32_t *__restrict__ perm, const uint32_t *__restrict__ totals, Xyzz<Fp2> *__restrict__ partial) {
     const int lane = threadIdx.x & 63, q = lane & 1;
@@ -982,34 +991,32 @@ k_msm_accum2c_l(const PtL2 *__restrict__ pts, const uint32_t *__restrict__ entri
     const Task tk = tasks[t];
     AccL2 acc;
     bool inf = true;                                           // uniform in the pair
+#pragma unroll 1
     for (uint32_t e = 0; e < tk.len; e++) {
-        const uint32_t ent = entries[tk.start + e];
-        const PtL2 *p = &pts[ent >> 1];
-        const int ys = (ent & 1u) ? 2 : 1;
-        const C2 qx{load_limbs(p->c[q][0]), load_limbs(p->c[q ^ 1][0])}, qy{load_limbs(p->c[q][ys]), load_limbs(p->c[q ^ 1][ys])};
+        const PtC2 pt = load_pt2(pts, entries[tk.start + e], q);
         if (inf) {
             const FpL one_q = q ? fpl_zero() : fpl_one();
-            acc = AccL2{qx.m, qy.m, one_q, one_q};
+            acc = AccL2{pt.x.m, pt.y.m, one_q, one_q};
             inf = false;
             continue;
         }
-        const C2 zz = with_partner(acc.zz), zzz = with_partner(acc.zzz);
-        const FpL P = subL<8>(mul_c<2>(qx, zz, q), acc.x);                     // < 10
-        const FpL R = subL<4>(mul_c<2>(qy, zzz, q), acc.y);                    // < 6
+        const FpL P = subL<8>(mul_c<2>(pt.x, with_partner(acc.zz), q), acc.x);      // < 10
+        const FpL R = subL<4>(mul_c<2>(pt.y, with_partner(acc.zzz), q), acc.y);     // < 6
         if (both2(is_zero_modp(P, 10), lane)) {
-            if (both2(is_zero_modp(R, 6), lane)) acc = dbl_affine2c_l(qx, qy, q);
+            if (both2(is_zero_modp(R, 6), lane)) acc = dbl_affine2c_l(pt.x, pt.y, q);
             else inf = true;
             continue;
         }
-        const C2 cP = with_partner(P), cR = with_partner(R);
+        // every operand's partner copy lives only as long as its products: zz' right behind PP, zzz' right behind PPP
+        const C2 cP = with_partner(P);
         const C2 PP = with_partner(sqr_c<10>(cP, q));
-        const FpL RR = sqr_c<6>(cR, q);
+        acc.zz = mul_c<2>(with_partner(acc.zz), PP, q);
         const C2 PPP = with_partner(mul_c<2>(cP, PP, q));
         const FpL Q = mul_c<2>(with_partner(acc.x), PP, q);
-        const FpL X3 = sub2L<4>(subL<2>(RR, PPP.m), Q);                        // R^2 - PPP - 2 Q + 6 p < 8
+        acc.zzz = mul_c<2>(with_partner(acc.zzz), PPP, q);
+        const C2 cR = with_partner(R);
+        const FpL X3 = sub2L<4>(subL<2>(sqr_c<6>(cR, q), PPP.m), Q);           // R^2 - PPP - 2 Q + 6 p < 8
         acc.y = mul_sub_c<10, 2>(cR, with_partner(subL<8>(Q, X3)), with_partner(acc.y), PPP, q);     // 2 x 6 x 10 + 2 x 4 x 2 < 630; < 2
-        acc.zz = mul_c<2>(zz, PP, q);
-        acc.zzz = mul_c<2>(zzz, PPP, q);
         acc.x = X3;
     }
     // back to the [0, 2p) words the fold and reduce kernels of G2 compute in
