@@ -26,6 +26,8 @@
 #include "codec.h"
 #include "lanes.h"
 #include "limb30.h"
+#include "dev_lanes.h"
+#include "g2_limb.h"
 #include "engine.h"
 
 namespace eip {
@@ -177,6 +179,9 @@ __device__ __forceinline__ FpL load_limbs(const uint32_t *src) {
 // Point record of the limb-form G2 accumulate (k_msm_accum2c_l): per Fp2 COMPONENT q the limbs of x_q R', y_q R' and -y_q R' -- the lane
 // that holds component q reads c[q] for its own operands and c[q ^ 1] for its partner's (no lane exchange for the loaded point).
 struct PtL2 { uint32_t c[2][3][14]; };
+// XYZZ point over Fp2 in limb form, as the G2 accumulate leaves it and the G2 fold / reduce kernels read it: per component q the limbs of
+// x_q, y_q, zz_q, zzz_q (standard bounds of g2_limb.h); infinity = all limbs 0
+struct Pt2L { uint32_t c[2][4][14]; };
 __device__ __forceinline__ void store_limb_record(void *, uint32_t, const Aff<Fp> &) {}
 __device__ __forceinline__ void store_limb_record(void *recs, uint32_t i, const Aff<Fp2> &a) {
     PtL2 *r = reinterpret_cast<PtL2 *>(recs) + i;
@@ -1019,9 +1024,13 @@ k_msm_accum2c_l(const PtL2 *__restrict__ pts, const uint32_t *__restrict__ entri
         acc.y = mul_sub_c<10, 2>(cR, with_partner(subL<8>(Q, X3)), with_partner(acc.y), PPP, q);     // 2 x 6 x 10 + 2 x 4 x 2 < 630; < 2
         acc.x = X3;
     }
-    // back to the [0, 2p) words the fold and reduce kernels of G2 compute in
-    const Xyzz<FpI> out = inf ? xyzz_inf<FpI>() : Xyzz<FpI>{to_fpi(acc.x), to_fpi(acc.y), to_fpi(acc.zz), to_fpi(acc.zzz)};
-    store_component(&partial[t], out, q);
+    // the task's sum stays in limbs: the G2 fold and reduce kernels compute in limb form too (g2_limb.h)
+    Pt2L *dst = reinterpret_cast<Pt2L *>(partial) + t;
+    const FpL z = fpl_zero();
+    store_limbs(dst->c[q][0], inf ? z : acc.x);
+    store_limbs(dst->c[q][1], inf ? z : acc.y);
+    store_limbs(dst->c[q][2], inf ? z : acc.zz);
+    store_limbs(dst->c[q][3], inf ? z : acc.zzz);
 }
 
 // ---- limb-form versions of the lane-split point operations (chain-bound G1 plans, c <= 13) -----------
@@ -1373,6 +1382,116 @@ k_msm_window_sum8c(const Xyzz<Fp2> *__restrict__ winout, MsmPlan pl, ReduceGrid 
     if (lane < 2) store_component(&winsum[w], C, q);
 }
 
+// ---- G2 fold / bucket reduce in limb form (g2_limb.h) ------------------------------------------------------
+// The same kernels as k_msm_fold_small8c / k_msm_reduce8c / k_msm_window_sum8c on the limb-form points that k_msm_accum2c_l leaves
+// (Pt2L): no re-slicing around the products, no conditional corrections, and no conversion between the accumulate and the reduce.
+// k_msm_fold_big8c_l replaces k_msm_fold_big<Fp2> (whole Fp2 values on every lane: 351 VGPRs + 944 B of scratch) on the path of
+// the heavy buckets.
+__device__ __forceinline__ XyzzK<1> load_pt2l(const Pt2L *p, int q) {
+    XyzzK<1> r;
+    r.x.l[0] = load_limbs(p->c[q][0]); r.y.l[0] = load_limbs(p->c[q][1]); r.zz.l[0] = load_limbs(p->c[q][2]); r.zzz.l[0] = load_limbs(p->c[q][3]);
+    return r;
+}
+__device__ __forceinline__ void store_pt2l(Pt2L *p, const XyzzK<1> &v, int q) {
+    store_limbs(p->c[q][0], v.x.l[0]); store_limbs(p->c[q][1], v.y.l[0]); store_limbs(p->c[q][2], v.zz.l[0]); store_limbs(p->c[q][3], v.zzz.l[0]);
+}
+__device__ __forceinline__ XyzzK<1> shfl_from(const XyzzK<1> &a, int src) {
+    XyzzK<1> r;
+    r.x.l[0] = shfl_from(a.x.l[0], src); r.y.l[0] = shfl_from(a.y.l[0], src); r.zz.l[0] = shfl_from(a.zz.l[0], src); r.zzz.l[0] = shfl_from(a.zzz.l[0], src);
+    return r;
+}
+// sum over the 8 groups of a wave (result in group 0), then over the block's 4 waves through LDS (result in the first group of wave 0)
+struct BlockSum8k { uint32_t c[4][2][4][14]; };
+__device__ __forceinline__ XyzzK<1> wave_sum8k(const DevLanes8 &x, XyzzK<1> C, int lane) {
+    for (int off = 8; off < 64; off <<= 1) {
+        const XyzzK<1> o = shfl_from(C, (lane + off) & 63);
+        if ((lane & (2 * off - 1)) < 8) C = add8k(x, C, o);
+    }
+    return C;
+}
+__device__ __forceinline__ XyzzK<1> block_sum8k(const DevLanes8 &x, XyzzK<1> C, BlockSum8k &sm, int lane, int wave) {
+    C = wave_sum8k(x, C, lane);
+    if (lane < 2) store_pt2l(reinterpret_cast<Pt2L *>(sm.c[wave]), C, x.q);
+    __syncthreads();
+    if (wave == 0 && lane < 8)
+        for (int k = 1; k < 4; k++) C = add8k(x, C, load_pt2l(reinterpret_cast<const Pt2L *>(sm.c[k]), x.q));
+    return C;
+}
+__global__ void __launch_bounds__(256)
+k_msm_fold_small8c_l(Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+                     const uint32_t *__restrict__ split_counts) {
+    const uint32_t n = split_counts[0];
+    const int sl = threadIdx.x & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    for (uint32_t h = blockIdx.x * 32u + (threadIdx.x >> 3); h < n; h += gridDim.x * 32u) {   // uniform in the group
+        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        XyzzK<1> acc = load_pt2l(&partial[t0], x.q);
+        for (uint32_t t = t0 + 1; t < t1; t++) acc = add8k(x, acc, load_pt2l(&partial[t], x.q));
+        if (sl < 2) store_pt2l(&partial[t0], acc, x.q);
+    }
+}
+// more than 8 tasks: one block per bucket -- 32 strided chains of 8-lane additions, shuffle tree, LDS step
+__global__ void __launch_bounds__(256)
+k_msm_fold_big8c_l(Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, const uint32_t *__restrict__ list,
+                   const uint32_t *__restrict__ split_counts) {
+    __shared__ BlockSum8k sm;
+    const uint32_t nh = split_counts[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t g = list[h], t0 = taskoff[g], t1 = taskoff[g + 1];
+        XyzzK<1> acc = xyzzk_inf<1>();
+        for (uint32_t t = t0 + (threadIdx.x >> 3); t < t1; t += 32u) acc = add8k(x, acc, load_pt2l(&partial[t], x.q));     // uniform in the group
+        acc = block_sum8k(x, acc, sm, lane, wave);
+        __syncthreads();                                       // every wave's read of partial[t0] and of sm is behind us
+        if (threadIdx.x < 2) store_pt2l(&partial[t0], acc, x.q);
+    }
+}
+// bucket reduce: a running sum per 8-lane group over a segment of S buckets (k_msm_reduce8c's map of blocks to windows)
+#ifndef EIP_G2L_RED_WAVES
+#define EIP_G2L_RED_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, EIP_G2L_RED_WAVES)
+k_msm_reduce8c_l(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, MsmPlan pl, ReduceGrid rg, Pt2L *__restrict__ blkout) {
+    __shared__ BlockSum8k sm;
+    int w;
+    uint32_t bx;
+    reduce_block_to_window(rg, pl, w, bx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    const uint32_t nbw = (w == pl.W - 1) ? pl.BT : pl.B;
+    const uint32_t seg = bx * 32u + (threadIdx.x >> 3);
+    const uint32_t lo = seg * pl.S;
+    XyzzK<1> C = xyzzk_inf<1>();
+    if (lo < nbw) {                                            // uniform in the group
+        const uint32_t hi = min(lo + pl.S, nbw);
+        XyzzK<1> R = xyzzk_inf<1>(), Q = xyzzk_inf<1>();
+        for (uint32_t v = hi; v > lo; v--) {
+            const uint32_t g = (uint32_t)w * pl.B + v - 1u;
+            const uint32_t t0 = taskoff[g], t1 = taskoff[g + 1];
+            if (t1 > t0) R = add8k(x, R, load_pt2l(&partial[t0], x.q));       // multi-task buckets were folded into slot t0
+            Q = add8k(x, Q, R);
+        }
+        C = add8k(x, Q, small_mul8k(x, R, lo));                // sum_{v in (lo, hi]} v * B_v = Q + lo * R
+    }
+    C = block_sum8k(x, C, sm, lane, wave);
+    if (threadIdx.x < 2) store_pt2l(&blkout[blockIdx.x], C, x.q);
+}
+// one wave per window adds the window's block sums and leaves the canonical point the host reads
+__global__ void __launch_bounds__(64)
+k_msm_window_sum8c_l(const Pt2L *__restrict__ blkout, MsmPlan pl, ReduceGrid rg, Xyzz<Fp2> *__restrict__ winsum) {
+    const int w = blockIdx.x, lane = threadIdx.x & 63, sl = lane & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
+    XyzzK<1> C = xyzzk_inf<1>();
+    for (uint32_t b = (uint32_t)(lane >> 3); b < nb; b += 8u) C = add8k(x, C, load_pt2l(&blkout[b0 + b], x.q));      // uniform in the group
+    C = wave_sum8k(x, C, lane);
+    if (lane < 2) {
+        const Xyzz<FpI> out{to_fpi(C.x.l[0]), to_fpi(C.y.l[0]), to_fpi(C.zz.l[0]), to_fpi(C.zzz.l[0])};
+        store_component(&winsum[w], out, x.q);
+    }
+}
+
 // ---- bucket reduce, one lane per running sum (used for G1) ------------------------------------
 // Measured at 2^20 / c = 16: 1.55 ms against 1.8-2.1 ms for the 4-lane form above (whose per-round
 // select / shuffle / stack traffic costs more than the Fp product it parallelises); over Fp2 the
@@ -1607,15 +1726,17 @@ static void launch_fold_small(hipStream_t s, bool four, bool limb, Xyzz<Fp> *par
     else
         hipLaunchKernelGGL(k_msm_fold_small<Fp>, dim3(512), dim3(256), 0, s, partial, taskoff, list, counts);
 }
-static void launch_fold_small(hipStream_t s, bool, bool, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
-    hipLaunchKernelGGL(k_msm_fold_small8c, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+static void launch_fold_small(hipStream_t s, bool, bool limb, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    if (limb) hipLaunchKernelGGL(k_msm_fold_small8c_l, dim3(1024), dim3(256), 0, s, reinterpret_cast<Pt2L *>(partial), taskoff, list, counts);
+    else hipLaunchKernelGGL(k_msm_fold_small8c, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
 }
 static void launch_fold_big(hipStream_t s, bool limb, Xyzz<Fp> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
     if (limb) hipLaunchKernelGGL((k_msm_fold_big<Fp, FpL>), dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
     else hipLaunchKernelGGL(k_msm_fold_big<Fp>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
 }
-static void launch_fold_big(hipStream_t s, bool, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
-    hipLaunchKernelGGL(k_msm_fold_big<Fp2>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
+static void launch_fold_big(hipStream_t s, bool limb, Xyzz<Fp2> *partial, const uint32_t *taskoff, const uint32_t *list, const uint32_t *counts) {
+    if (limb) hipLaunchKernelGGL(k_msm_fold_big8c_l, dim3(1024), dim3(256), 0, s, reinterpret_cast<Pt2L *>(partial), taskoff, list, counts);
+    else hipLaunchKernelGGL(k_msm_fold_big<Fp2>, dim3(1024), dim3(256), 0, s, partial, taskoff, list, counts);
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout, const RcpGeom *rcp, Xyzz<FpL> *rc) {
@@ -1630,8 +1751,14 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool li
     else if (four) hipLaunchKernelGGL(k_msm_reduce4<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
-static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
+static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool limb, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout, const RcpGeom *, Xyzz<FpL> *) {
+    if (limb) {                 // limb-form block sums live behind the W canonical window sums
+        Pt2L *blkout = reinterpret_cast<Pt2L *>(winout + red_blocks + pl.W);
+        hipLaunchKernelGGL(k_msm_reduce8c_l, dim3(red_blocks), dim3(256), 0, s, reinterpret_cast<const Pt2L *>(partial), taskoff, pl, rg, blkout);
+        hipLaunchKernelGGL(k_msm_window_sum8c_l, dim3(pl.W), dim3(64), 0, s, (const Pt2L *)blkout, pl, rg, winout + red_blocks);
+        return;
+    }
     hipLaunchKernelGGL(k_msm_reduce8c, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
     hipLaunchKernelGGL(k_msm_window_sum8c, dim3(pl.W), dim3(64), 0, s, (const Xyzz<Fp2> *)winout, pl, rg, winout + red_blocks);     // -> W window sums behind the block sums
 }
@@ -1831,8 +1958,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
     HIPCHK(e->entries.reserve((size_t)pl.W * ns_max * 4));
     HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
-    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : sizeof(Xyzz<F>))));
-    HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>)));
+    HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : g2_limb ? sizeof(Pt2L) : sizeof(Xyzz<F>))));
+    HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>) + (g2_limb ? (size_t)red_blocks * sizeof(Pt2L) : 0)));
     HIPCHK(e->misc.reserve(64));
     HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
     HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
@@ -1966,9 +2093,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             // c <= 13 plans: the accumulate is chain-bound, two lanes per task (G1 2^16 1.15 -> 1.07 ms, 2^17 1.67 -> 1.48 ms)
             launch_accum(s, task_blocks, pl.c <= 13, pts, limb_recs, entries, tasks, perm, totals, partial);
             HIPCHK(hipEventRecord(e->ev_b, s));
-            launch_fold_small(s, four, limb_form, partial, taskoff, split_small, totals + 2);
-            launch_fold_big(s, limb_form, partial, taskoff, split_big, totals + 2);
-            launch_reduce(s, red_blocks, four, limb_form, partial, taskoff, pl, rg, winout, two_level_p ? &rcp : nullptr, reinterpret_cast<Xyzz<FpL> *>(e->rcsum.p));
+            launch_fold_small(s, four, limb_form || g2_limb, partial, taskoff, split_small, totals + 2);
+            launch_fold_big(s, limb_form || g2_limb, partial, taskoff, split_big, totals + 2);
+            launch_reduce(s, red_blocks, four, limb_form || g2_limb, partial, taskoff, pl, rg, winout, two_level_p ? &rcp : nullptr, reinterpret_cast<Xyzz<FpL> *>(e->rcsum.p));
         }
     }
     HIPCHK(hipEventRecord(e->ev_stop, s));

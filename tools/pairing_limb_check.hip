@@ -8,6 +8,7 @@
 #include "pairing.h"
 #include "h2c.h"
 #include "pairing_limb.h"
+#include "g2_limb.h"
 using namespace eip;
 static uint64_t g_s = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() { g_s ^= g_s << 13; g_s ^= g_s >> 7; g_s ^= g_s << 17; return g_s; }
@@ -292,5 +293,52 @@ int main() {
             if (!eq(canon_of(elem_load(eh.data(), k, 0)), w[k].c0) || !eq(canon_of(elem_load(eh.data(), k, 1)), w[k].c1)) bad5++;
     }
     printf("dense products: %ld mismatches\n", bad5);
-    return (bad || bad1 || bad2 || bad3 || bad4 || bad5) ? 1 : 0;
+    // ---- XYZZ points over Fp2 on 8 lanes (g2_limb.h: the G2 fold / bucket reduce) against curve.h ----
+    long bad6 = 0;
+    {
+        auto to_k = [&](const Xyzz<Fp2> &a) {
+            XyzzK<8> r;
+            for (int i = 0; i < 8; i++) {
+                const bool inf = is_zero(a.zz);
+                r.x.l[i] = inf ? fpl_zero() : lift_big<8>((i & 1) ? a.x.c1 : a.x.c0);
+                r.y.l[i] = inf ? fpl_zero() : lift_big<4>((i & 1) ? a.y.c1 : a.y.c0);
+                r.zz.l[i] = inf ? fpl_zero() : lift_big<2>((i & 1) ? a.zz.c1 : a.zz.c0);
+                r.zzz.l[i] = inf ? fpl_zero() : lift_big<2>((i & 1) ? a.zzz.c1 : a.zzz.c0);
+            }
+            return r;
+        };
+        auto same = [&](const XyzzK<8> &got, const Xyzz<Fp2> &want) {
+            if (!lanes_agree(got.x) || !lanes_agree(got.y) || !lanes_agree(got.zz) || !lanes_agree(got.zzz)) return false;
+            const bool ginf = is_inf8k(x8, got);
+            if (ginf || is_zero(want.zz)) return ginf && is_zero(want.zz);
+            const Aff<Fp2> a = to_affine(Xyzz<Fp2>{join_q(got.x), join_q(got.y), join_q(got.zz), join_q(got.zzz)}), b = to_affine(want);
+            return eq(a.x, b.x) && eq(a.y, b.y);
+        };
+        auto lifted = [&](const Aff<Fp2> &a) {              // a random XYZZ representative of an affine point
+            const Fp2 l = rnd_fp2(), ll = sqr(l), lll = mul(ll, l);
+            return Xyzz<Fp2>{mul(a.x, ll), mul(a.y, lll), ll, lll};
+        };
+        const Xyzz<Fp2> inf = xyzz_inf<Fp2>();
+        for (int it = 0; it < 200; it++) {
+            const Aff<Fp2> A = (it % 5 == 4) ? map_to_curve<Fp2>(rnd_fp2()) : rnd_multiple(g2_gen()), B = rnd_multiple(g2_gen());
+            const Xyzz<Fp2> a = lifted(A), b = lifted(B), a2 = lifted(A), na = Xyzz<Fp2>{a2.x, neg(a2.y), a2.zz, a2.zzz};
+            if (!same(add8k(x8, to_k(a), to_k(b)), add(a, b))) bad6++;
+            if (!same(add8k(x8, to_k(a), to_k(a2)), dbl(a))) bad6++;                 // equal points in different representatives
+            if (!same(add8k(x8, to_k(a), to_k(na)), inf)) bad6++;                   // opposite points
+            if (!same(add8k(x8, to_k(a), to_k(inf)), a) || !same(add8k(x8, to_k(inf), to_k(b)), b)) bad6++;
+            if (!same(dbl8k(x8, to_k(a)), dbl(a)) || !same(dbl8k(x8, to_k(inf)), inf)) bad6++;
+            const uint32_t m = it < 40 ? (uint32_t)it : (uint32_t)(rnd() % 5000);
+            Xyzz<Fp2> want = inf;
+            for (int bit = 12; bit >= 0; bit--) { want = dbl(want); if ((m >> bit) & 1u) want = add(want, a); }
+            if (!same(small_mul8k(x8, to_k(a), m), want) || !same(small_mul8k(x8, to_k(inf), m), inf)) bad6++;
+            // the running sums of a reduce segment: sum_{v = 1..4} v B_v with an empty bucket in the middle
+            const Xyzz<Fp2> bk[4] = {a, inf, b, a2};
+            XyzzK<8> R = xyzzk_inf<8>(), Q = xyzzk_inf<8>();
+            Xyzz<Fp2> Rw = inf, Qw = inf;
+            for (int v = 3; v >= 0; v--) { R = add8k(x8, R, to_k(bk[v])); Q = add8k(x8, Q, R); Rw = add(Rw, bk[v]); Qw = add(Qw, Rw); }
+            if (!same(Q, Qw)) bad6++;
+        }
+    }
+    printf("G2 XYZZ on 8 lanes: %ld mismatches\n", bad6);
+    return (bad || bad1 || bad2 || bad3 || bad4 || bad5 || bad6) ? 1 : 0;
 }
