@@ -459,8 +459,11 @@ def main():
                         % (plan["windows"], plan.get("window_bits", 0), MADS_PER_FP_PRODUCT)}
             # multiply-adds the G1 kernels really execute per mixed addition: the two squarings take 260 of them
             # (91 + 169), and the limb-form kernel reduces R (Q - x3) - y1 PPP once (338 + 169)
+            # G2 (two lanes per addition): k_msm_accum2c ten two-product sums per lane (507 each); k_msm_accum2c_l six of them, two
+            # squares as one product each (338) and Y3 as one four-product sum (4 x 169 + 169) per lane
             executed = {"k_msm_accum_l": 6 * 338 + 2 * 260 + 507, "k_msm_accum<eip::Fp>": 8 * 338 + 2 * 260,
-                        "k_msm_accum2<eip::Fp>": 8 * 338 + 2 * 260}.get(plan.get("kernel"))
+                        "k_msm_accum2<eip::Fp>": 8 * 338 + 2 * 260, "k_msm_accum2c": 2 * 10 * 507,
+                        "k_msm_accum2c_l": 2 * (6 * 507 + 2 * 338 + 845)}.get(plan.get("kernel"))
             if executed:
                 result["roofline_valu"]["mads_executed_per_addition"] = executed
                 result["roofline_valu"]["frac_executed"] = n_local * plan["windows"] * executed / (k_ms * 1e-3) / MAD_PEAK

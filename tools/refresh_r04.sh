@@ -13,7 +13,7 @@ step prof g2msm 2^16;  timeout -k 10 400 bash tools/prof_kernels.sh r04_g2msm_2p
 step prof g1msm 2^16;  timeout -k 10 400 bash tools/prof_kernels.sh r04_g1msm_2p16 --workload g1msm --log2n 16 --steps 10 --warmup 2 --no-secondary > $O/prof_g1_16.log 2>&1 || exit 1
 cp gpurun_out/r04_*_kernels.csv $O/ && cp gpurun_out/r04_*_kernels.csv profiles/
 python tools/make_traffic_json.py r04 g1msm:20:profiles/r04_g1msm_2p20_kernels.csv:k_msm_accum_l pairing:12:profiles/r04_pairing_2p12_kernels.csv:k_pair_lines8 \
-       g2msm:16:profiles/r04_g2msm_2p16_kernels.csv:k_msm_accum2c > $O/traffic.log 2>&1 && cp profiles/r04_traffic.json $O/
+       g2msm:16:profiles/r04_g2msm_2p16_kernels.csv:k_msm_accum2c_l > $O/traffic.log 2>&1 && cp profiles/r04_traffic.json $O/
 step bench default;    timeout -k 10 600 python bench.py > $O/r04_bench_default.json 2> $O/bench_default.err || exit 1
 step bench g2msm;      timeout -k 10 400 python bench.py --workload g2msm > $O/r04_bench_g2msm_2p16.json 2> $O/bench_g2.err || exit 1
 step bench pairing;    timeout -k 10 400 python bench.py --workload pairing > $O/r04_bench_pairing_2p12.json 2> $O/bench_pair.err || exit 1
