@@ -210,6 +210,8 @@ static void slot_reset(Engine &e) {
     for (hipEvent_t *v : {&e.ev_start, &e.ev_stop, &e.ev_a, &e.ev_b, &e.ev_j2, &e.ev_j3, &e.ev_c}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
     for (hipEvent_t &v : e.ev_copy) { if (v) (void)hipEventDestroy(v); v = nullptr; }
     if (e.pinned) { (void)hipHostFree(e.pinned); e.pinned = nullptr; e.pinned_cap = 0; }
+    for (hipEvent_t &v : e.ev_sorted) { if (v) (void)hipEventDestroy(v); v = nullptr; }
+    for (hipEvent_t &v : e.ev_accdone) { if (v) (void)hipEventDestroy(v); v = nullptr; }
     e.release_workspace();
     e.ready = false;
     e.failed = false;
@@ -362,9 +364,9 @@ static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_in
         e->host_src = in;
         e->copy_gate = gate;
         e->copy_turn = turn;
-        if (feed) e->feed = *feed;                  // staged shard by shard into one bucket space (msm.hip)
         d_in = e->input.p;
     }
+    if (feed) e->feed = *feed;                      // record shards of one bucket space (msm.hip): staged copies | sort beside accumulate
     Xyzz<F> acc;
     int st = msm_dispatch<F>(e, d_in, n, reinterpret_cast<uint32_t *>(&acc));
     e->host_src = nullptr;                      // never retained past the call (an early error return leaves it set)
@@ -378,11 +380,57 @@ static int msm_entry(int pi, byte *out, const void *in, size_t n, bool device_in
     }
     return E_SUCCESS;
 }
+static std::vector<uint32_t> parse_weights(const char *v) {
+    std::vector<uint32_t> w;
+    if (v)
+        for (const char *c = v; *c;) {
+            char *endp = nullptr;
+            const unsigned long x = strtoul(c, &endp, 10);
+            if (endp == c) break;
+            w.push_back((uint32_t)x);
+            c = *endp == ',' ? endp + 1 : endp;
+        }
+    return w;
+}
+static ShardFeed feed_from_weights(size_t n, const std::vector<uint64_t> &w) {
+    ShardFeed f;
+    uint64_t total = 0;
+    for (uint64_t x : w) total += x;
+    if (w.size() < 2 || !total) return f;
+    uint64_t run = 0;
+    f.bound[0] = 0;
+    int k = 0;
+    for (size_t i = 0; i < w.size(); i++) {
+        run += w[i];
+        const uint32_t b = i + 1 == w.size() ? (uint32_t)n : (uint32_t)((unsigned __int128)n * run / total);
+        if (b > f.bound[k]) f.bound[++k] = b;          // empty shards vanish
+    }
+    f.k = k;
+    return f;
+}
+// Record shards of a device-resident G1 call (EIP2537_DEV_STAGES=k | w0,w1,...; 0 or 1: one shard).  Default: from 2^21 records equal
+// shards of 2^19 (at most 8).  Measured (profiles/r04_dev_shards.txt): 2^21 6.06 -> 5.88 ms, 2^22 11.9 -> 10.9 ms; at 2^20 every cut
+// loses (3.22 -> 3.29 .. 3.6: a shard's extra tasks and bucket-accumulator round trips cost more than the hidden sort stage saves).
+static ShardFeed stage_plan_dev(size_t n) {
+    static const std::vector<uint32_t> env = parse_weights(getenv("EIP2537_DEV_STAGES"));
+    if (g_window_override.load() != 0 || n >= ((size_t)1 << 31)) return ShardFeed{};
+    std::vector<uint64_t> w;
+    if (env.size() == 1) { if (env[0] >= 2) w.assign(std::min<size_t>(env[0], ShardFeed::kMax), 1u); }
+    else if (env.size() > 1) w.assign(env.begin(), env.begin() + std::min<size_t>(env.size(), ShardFeed::kMax));
+    else if (n >= ((size_t)1 << 21)) w.assign(std::min<size_t>(ShardFeed::kMax, n >> 19), 1u);
+    return feed_from_weights(n, w);
+}
 template <class F> static int msm_dev_abi(byte *out, const void *d_in, size_t n, bool want_partial) {
     if (!n) return E_INVALID_LENGTH;
     int pi = pool_of_pointer(d_in);
     if (pi == -2) { fprintf(stderr, "[eip2537_hip] %p is not device memory\n", d_in); return E_MEMORY_ERROR; }
     if (pi < 0) return E_MEMORY_ERROR;
+    if (std::is_same<F, Fp>::value) {
+        // a large device-resident G1 input is cut into record shards of one bucket space too: the sort stage of shard s + 1 then runs
+        // beside the accumulate of shard s (msm.hip), and every shard's limb records stay inside the last-level cache
+        const ShardFeed feed = stage_plan_dev(n);
+        if (feed.k > 1) return msm_entry<F>(pi, out, d_in, n, true, want_partial, nullptr, 0, &feed);
+    }
     return msm_entry<F>(pi, out, d_in, n, true, want_partial);
 }
 
@@ -711,45 +759,21 @@ template <class F> static size_t pipeline_shards(size_t n) {
 // (which visit all 557 056 buckets whatever the shard holds) stop paying for the overlap (profiles/r04_h2d_stages.txt).
 // $EIP2537_H2D_STAGES: "k" = k equal shards, or a comma list of relative shard weights (A/B); EIP2537_H2D_PIPELINE=0: one copy.
 static ShardFeed stage_plan_g1(size_t n) {
-    ShardFeed f;
     static const int mode = [] { const char *v = getenv("EIP2537_H2D_PIPELINE"); return v ? atoi(v) : 1; }();
-    static const std::vector<uint32_t> env = [] {
-        std::vector<uint32_t> w;
-        if (const char *v = getenv("EIP2537_H2D_STAGES"))
-            for (const char *c = v; *c;) {
-                char *endp = nullptr;
-                const unsigned long x = strtoul(c, &endp, 10);
-                if (endp == c) break;
-                w.push_back((uint32_t)x);
-                c = *endp == ',' ? endp + 1 : endp;
-            }
-        return w;
-    }();
-    if (mode == 0 || g_window_override.load() != 0 || n >= ((size_t)1 << 31)) return f;
+    static const std::vector<uint32_t> env = parse_weights(getenv("EIP2537_H2D_STAGES"));
+    if (mode == 0 || g_window_override.load() != 0 || n >= ((size_t)1 << 31)) return ShardFeed{};
     // (only the c = 16 plans, n > 2^17, share buckets: msm.hip takes any other call in one copy whatever is asked for here)
     std::vector<uint64_t> w;
     if (env.size() == 1) w.assign(std::min<size_t>(env[0], ShardFeed::kMax), 1u);
     else if (env.size() > 1) w.assign(env.begin(), env.begin() + std::min<size_t>(env.size(), ShardFeed::kMax));
     else {
-        if (n < ((size_t)1 << 19)) return f;
+        if (n < ((size_t)1 << 19)) return ShardFeed{};
         const size_t first = (size_t)1 << 16;
         const size_t rest = std::min<size_t>(ShardFeed::kMax - 1, std::max<size_t>(1, (n - first + ((size_t)1 << 17)) >> 18));
         w.push_back(first);
         for (size_t i = 0; i < rest; i++) w.push_back((n - first) / rest);
     }
-    uint64_t total = 0;
-    for (uint64_t x : w) total += x;
-    if (w.size() < 2 || !total) return f;
-    uint64_t run = 0;
-    f.bound[0] = 0;
-    int k = 0;
-    for (size_t i = 0; i < w.size(); i++) {
-        run += w[i];
-        const uint32_t b = i + 1 == w.size() ? (uint32_t)n : (uint32_t)((unsigned __int128)n * run / total);
-        if (b > f.bound[k]) f.bound[++k] = b;          // empty shards vanish
-    }
-    f.k = k;
-    return f;
+    return feed_from_weights(n, w);
 }
 static int least_busy_pool() {
     std::lock_guard<std::mutex> lk(g_mu);

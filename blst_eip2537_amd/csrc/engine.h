@@ -178,6 +178,7 @@ struct Engine {
     hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr, ev_j2 = nullptr, ev_j3 = nullptr, ev_c = nullptr;
     hipEvent_t ev_copy[ShardFeed::kMax] = {};      // behind the copy of every shard of a staged host-input call (stream2)
+    hipEvent_t ev_sorted[ShardFeed::kMax] = {}, ev_accdone[ShardFeed::kMax] = {};      // staged call: sort stage (stream3) <-> accumulate (stream) of a shard
     Helper helper;                                 // stages those copies
     ShardFeed feed;                                // set with host_src by a staged call (k > 1)
     // staging + per-call workspace (grow-only)

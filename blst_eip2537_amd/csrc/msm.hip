@@ -1906,8 +1906,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
 
     // Record shards: [bound[s], bound[s + 1]).  Only a two-level plan can share its buckets between shards; anything else takes
     // the caller's buffer in one copy.
-    const bool staged = two_level && host_src && feed.k > 1 && feed.k <= ShardFeed::kMax && feed.bound[0] == 0u && feed.bound[feed.k] == (uint32_t)n;
-    if (!staged) { feed.k = 1; feed.bound[0] = 0u; feed.bound[1] = (uint32_t)n; }
+    const bool sharded = two_level && feed.k > 1 && feed.k <= ShardFeed::kMax && feed.bound[0] == 0u && feed.bound[feed.k] == (uint32_t)n;
+    const bool staged = sharded && host_src;           // the shards are copied from the caller's buffer one behind the other
+    if (!sharded) { feed.k = 1; feed.bound[0] = 0u; feed.bound[1] = (uint32_t)n; }
     const int K = feed.k;
     // task length limit L = 2^lshift: at least twice the mean bucket load so that split buckets stay
     // the exception (they cost an extra fold pass), and at least kMinTaskShift.  Below ~2^18 records
@@ -1936,7 +1937,15 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // G2: the accumulate in limb form too (k_msm_accum2c_l; fold and reduce stay in FpI words); EIP2537_G2_LIMB=0: k_msm_accum2c
     static const bool env_g2limb = [] { const char *v = getenv("EIP2537_G2_LIMB"); return !v || atoi(v) != 0; }();
     const bool g2_limb = ReduceCfg<F>::kFourLane && env_g2limb;
-    HIPCHK(e->pts.reserve((size_t)ns_max * (limb_form ? sizeof(PtL) : g2_limb ? sizeof(PtL2) : sizeof(Aff<F>))));
+    // Sharded call: the SORT stage of shard s + 1 (decode .. task order: latency- and LDS-bound kernels that leave the vector units idle)
+    // runs on stream3 beside the ACCUMULATE of shard s on the main stream.  Everything the accumulate / fold kernels read from the sort
+    // stage exists twice (by shard parity); events order sort(s) -> accumulate(s) and accumulate(s) -> sort(s + 2).
+    // EIP2537_SORT_OVERLAP=0: one stream, one set (A/B).
+    static const bool env_overlap = [] { const char *v = getenv("EIP2537_SORT_OVERLAP"); return !v || atoi(v) != 0; }();
+    const bool overlap = sharded && !host_src && K > 1 && env_overlap;
+    const size_t dup = overlap ? 2 : 1;
+    const size_t pt_bytes = limb_form ? sizeof(PtL) : g2_limb ? sizeof(PtL2) : sizeof(Aff<F>);
+    HIPCHK(e->pts.reserve(dup * (size_t)ns_max * pt_bytes));
     HIPCHK(e->counts.reserve((size_t)pl.NB * 4));
     HIPCHK(e->offsets.reserve((size_t)pl.NB * 4));
     const uint32_t nbmax = (std::max(pl.B, pl.BT) + 1u) & ~1u;
@@ -1955,19 +1964,19 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     HIPCHK(e->hist16.reserve(hist_bytes));
     HIPCHK(e->slice_base.reserve(base_bytes));
-    HIPCHK(e->taskoff.reserve((size_t)(pl.NB + 1) * 4));
-    HIPCHK(e->entries.reserve((size_t)pl.W * ns_max * 4));
-    HIPCHK(e->tasks.reserve((size_t)pl.max_tasks * sizeof(Task)));
+    HIPCHK(e->taskoff.reserve(dup * (size_t)(pl.NB + 1) * 4));
+    HIPCHK(e->entries.reserve(dup * (size_t)pl.W * ns_max * 4));
+    HIPCHK(e->tasks.reserve(dup * (size_t)pl.max_tasks * sizeof(Task)));
     HIPCHK(e->partial.reserve((size_t)pl.max_tasks * (limb_form ? sizeof(Xyzz<FpL>) : g2_limb ? sizeof(Pt2L) : sizeof(Xyzz<F>))));
     HIPCHK(e->winout.reserve(((size_t)red_blocks + (size_t)pl.W) * sizeof(Xyzz<F>) + (g2_limb ? (size_t)red_blocks * sizeof(Pt2L) : 0)));
-    HIPCHK(e->misc.reserve(64));
-    HIPCHK(e->scan_blk.reserve(kScanBlkWords * 4));         // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
-    HIPCHK(e->perm.reserve((size_t)pl.max_tasks * 4));
-    HIPCHK(e->split_lists.reserve((size_t)pl.NB * 8));      // split-bucket lists: small | big
+    HIPCHK(e->misc.reserve(64));                            // first-error word | heavy flag | totals (x2)
+    HIPCHK(e->scan_blk.reserve(dup * kScanBlkWords * 4));   // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
+    HIPCHK(e->perm.reserve(dup * (size_t)pl.max_tasks * 4));
+    HIPCHK(e->split_lists.reserve(dup * (size_t)pl.NB * 8));      // split-bucket lists: small | big
     if (two_level_p) HIPCHK(e->rcsum.reserve((size_t)pl.W * 128u * sizeof(Xyzz<FpL>)));      // per window: 64 row + 64 column sums
     if (two_level) {
         HIPCHK(e->bacc.reserve((size_t)pl.NB * sizeof(Xyzz<FpL>)));
-        HIPCHK(e->taskbkt.reserve((size_t)pl.max_tasks * 4));
+        HIPCHK(e->taskbkt.reserve(dup * (size_t)pl.max_tasks * 4));
         HIPCHK(e->rcsum.reserve(rc_bytes));
     }
     if ((pl.NB + 1023u) / 1024u > 1024u) return E_MEMORY_ERROR;
@@ -1975,31 +1984,28 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     static const uint32_t env_sp = [] { const char *v = getenv("EIP2537_SCATTER_PASSES"); return v ? (uint32_t)atoi(v) : 0u; }();
     hipStream_t s = e->stream;
     auto *err = reinterpret_cast<unsigned long long *>(e->misc.p);
-    auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16);
-    HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, s));
     uint32_t *heavy = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 8);        // raised by k_sort_coarse_scan: degenerate input
-    HIPCHK(hipMemsetAsync(heavy, 0, 8, s));
+    hipStream_t ss = s;                          // the stream of the sort stage
+    if (overlap) {
+        HIPCHK(e->need_stream3());
+        ss = e->stream3;
+        for (int sh = 0; sh < K; sh++) {
+            if (!e->ev_sorted[sh]) HIPCHK(hipEventCreateWithFlags(&e->ev_sorted[sh], hipEventDisableTiming));
+            if (!e->ev_accdone[sh]) HIPCHK(hipEventCreateWithFlags(&e->ev_accdone[sh], hipEventDisableTiming));
+        }
+    }
+    HIPCHK(hipMemsetAsync(e->misc.p, 0xFF, 8, ss));      // (on the stream whose first kernel, the decode, writes the error word)
+    HIPCHK(hipMemsetAsync(heavy, 0, 8, ss));
 
     const size_t rec_words = Wire<F>::kMsmRecWords, rec_bytes = rec_words * 4;
-    auto *pts = reinterpret_cast<Aff<F> *>(e->pts.p);
     auto *digits = reinterpret_cast<uint32_t *>(e->digits.p);
     auto *counts = reinterpret_cast<uint32_t *>(e->counts.p);
     auto *offsets = reinterpret_cast<uint32_t *>(e->offsets.p);
     auto *hist16 = reinterpret_cast<uint32_t *>(e->hist16.p);
     auto *base = reinterpret_cast<uint32_t *>(e->slice_base.p);
-    auto *taskoff = reinterpret_cast<uint32_t *>(e->taskoff.p);
-    auto *entries = reinterpret_cast<uint32_t *>(e->entries.p);
-    auto *tasks = reinterpret_cast<Task *>(e->tasks.p);
     auto *partial = reinterpret_cast<Xyzz<F> *>(e->partial.p);
     auto *winout = reinterpret_cast<Xyzz<F> *>(e->winout.p);
-    auto *perm = reinterpret_cast<uint32_t *>(e->perm.p);
-    uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p), *split_big = split_small + pl.NB;
-    auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p);
-    uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges;
-    uint32_t *taskbkt = two_level ? reinterpret_cast<uint32_t *>(e->taskbkt.p) : nullptr;
     Xyzz<FpL> *bacc = two_level ? reinterpret_cast<Xyzz<FpL> *>(e->bacc.p) : nullptr;
-    PtL *ptl = limb_form ? reinterpret_cast<PtL *>(e->pts.p) : nullptr;
-    void *limb_recs = (limb_form || g2_limb) ? e->pts.p : nullptr;          // PtL (G1) | PtL2 (G2) records in place of the affine points
 
     {
         const bool two_lane = ReduceCfg<F>::kFourLane || pl.c <= 13;
@@ -2036,53 +2042,72 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         const uint32_t scatter_passes = env_sp ? env_sp : (ns >= (1u << 19) ? 4u : ns >= (1u << 18) ? 2u : 1u);   // measured: profiles/r02_scatter_passes.txt
         const uint32_t *in = reinterpret_cast<const uint32_t *>(d_in) + (size_t)r0 * rec_words;
         const uint32_t split_g = last ? split_top : 0xffffffffu;          // earlier shards: one task order, one accumulate launch
+        // what the accumulate / fold kernels read from the sort stage: one set per shard parity when the two overlap
+        const size_t par = overlap ? (size_t)(sh & 1) : 0;
+        auto *pts = reinterpret_cast<Aff<F> *>(static_cast<char *>(e->pts.p) + par * (size_t)ns_max * pt_bytes);
+        PtL *ptl = limb_form ? reinterpret_cast<PtL *>(pts) : nullptr;
+        void *limb_recs = (limb_form || g2_limb) ? static_cast<void *>(pts) : nullptr;      // PtL (G1) | PtL2 (G2) records in place of the affine points
+        auto *taskoff = reinterpret_cast<uint32_t *>(e->taskoff.p) + par * (size_t)(pl.NB + 1);
+        auto *entries = reinterpret_cast<uint32_t *>(e->entries.p) + par * (size_t)pl.W * ns_max;
+        auto *tasks = reinterpret_cast<Task *>(e->tasks.p) + par * (size_t)pl.max_tasks;
+        auto *perm = reinterpret_cast<uint32_t *>(e->perm.p) + par * (size_t)pl.max_tasks;
+        uint32_t *split_small = reinterpret_cast<uint32_t *>(e->split_lists.p) + par * 2u * (size_t)pl.NB, *split_big = split_small + pl.NB;
+        auto *blk = reinterpret_cast<uint32_t *>(e->scan_blk.p) + par * kScanBlkWords;
+        uint32_t *lenhist = blk + kLenHist, *lenoff = blk + kLenOff, *ranges = blk + kRanges;
+        uint32_t *taskbkt = two_level ? reinterpret_cast<uint32_t *>(e->taskbkt.p) + par * (size_t)pl.max_tasks : nullptr;
+        auto *totals = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->misc.p) + 16 + 16 * par);
         if (staged && !inline_copies) {
             if (!staged_copy.wait_shard(sh)) {
                 fprintf(stderr, "[eip2537_hip] host-to-device copy of shard %d failed\n", sh);
                 e->failed = true;
                 return E_MEMORY_ERROR;
             }
-            HIPCHK(hipStreamWaitEvent(s, e->ev_copy[sh], 0));
+            HIPCHK(hipStreamWaitEvent(ss, e->ev_copy[sh], 0));
         } else if (host_src) {
             // Measured (profiles/r03_h2d_chunks.txt): chunking ONE pipeline's copy with decode + histograms behind every chunk lost
             // (7.31 -> 7.51 .. 8.08 ms at 2^20: only 0.2 ms of work could follow a chunk); that code is gone.
-            const hipError_t ce = hipMemcpyAsync(const_cast<uint32_t *>(in), static_cast<const char *>(host_src) + (size_t)r0 * rec_bytes, (size_t)ns * rec_bytes, hipMemcpyHostToDevice, s);
+            const hipError_t ce = hipMemcpyAsync(const_cast<uint32_t *>(in), static_cast<const char *>(host_src) + (size_t)r0 * rec_bytes, (size_t)ns * rec_bytes, hipMemcpyHostToDevice, ss);
             if (e->copy_gate) e->copy_gate->done(e->copy_turn);            // shards of one call on one device copy in shard order (api.hip); a pageable copy returns when its last chunk is staged
             HIPCHK(ce);
         }
-        // totals: [0] entries [1] tasks [2] lightly split [3] heavily split buckets -- written / cleared by k_msm_scan_sums' last block
-        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, s, in, ps, pts, limb_recs, digits, err, r0);
-        if (!sort2 && small_lds) hipLaunchKernelGGL(k_msm_hist<4096u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
-        else if (!sort2) hipLaunchKernelGGL(k_msm_hist<kLdsWords>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, nbmax, hist16, 0u);
+        if (overlap && sh >= 2) HIPCHK(hipStreamWaitEvent(ss, e->ev_accdone[sh - 2], 0));      // this parity's set is free again
+        // totals: [0] entries [1] tasks [2] lightly split [3] heavily split buckets -- written / cleared by k_msm_scan_top
+        hipLaunchKernelGGL(k_msm_decode<F>, dim3(rec_blocks), dim3(256), 0, ss, in, ps, pts, limb_recs, digits, err, r0);
+        if (!sort2 && small_lds) hipLaunchKernelGGL(k_msm_hist<4096u>, dim3(nslices, pl.W), dim3(1024), 0, ss, digits, ps, nslices, nbmax, hist16, 0u);
+        else if (!sort2) hipLaunchKernelGGL(k_msm_hist<kLdsWords>, dim3(nslices, pl.W), dim3(1024), 0, ss, digits, ps, nslices, nbmax, hist16, 0u);
         const uint32_t scan_blocks = (pl.NB + 1023u) / 1024u;      // <= 1024 (c <= 16)
         if (sort2) {
             // a degenerate input (k_sort_coarse_scan raises `heavy`) leaves every bucket empty here; the host then re-runs the call with
             // the direct scatter (below).  Round 3 launched the direct-scatter kernels behind these with the flag as their condition:
             // three empty launches (17 us) in every shard of every ordinary call.
             uint32_t *wtotal = blk + kWTotal, *wbase = blk + kWBase;
-            hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, heavy);
-            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, s, hist16, ps, nslices, wtotal, heavy);
-            hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, s, wtotal, pl.W, wbase);
+            hipLaunchKernelGGL(k_sort_coarse_hist, dim3(nslices, pl.W), dim3(1024), 0, ss, digits, ps, nslices, hist16, heavy);
+            hipLaunchKernelGGL(k_sort_coarse_scan, dim3(pl.W), dim3(1024), 0, ss, hist16, ps, nslices, wtotal, heavy);
+            hipLaunchKernelGGL(k_sort_window_bases, dim3(1), dim3(64), 0, ss, wtotal, pl.W, wbase);
             if (ps.slice <= 16384u)
-                hipLaunchKernelGGL(k_sort_coarse_scatter<16384u>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+                hipLaunchKernelGGL(k_sort_coarse_scatter<16384u>, dim3(nslices, pl.W), dim3(1024), 0, ss, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
             else
-                hipLaunchKernelGGL(k_sort_coarse_scatter<kSlice>, dim3(nslices, pl.W), dim3(1024), 0, s, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
-            hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, s, base, ps, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
+                hipLaunchKernelGGL(k_sort_coarse_scatter<kSlice>, dim3(nslices, pl.W), dim3(1024), 0, ss, digits, ps, nslices, hist16, wbase, base, (const uint32_t *)heavy);
+            hipLaunchKernelGGL(k_sort_fine, dim3(std::max(pl.B, pl.BT) >> kFineBits, pl.W), dim3(512), 0, ss, base, ps, nslices, hist16, wbase, entries, counts, (const uint32_t *)heavy);
         } else {
-            hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, s, hist16, ps, nslices, nbmax, base, counts);
+            hipLaunchKernelGGL(k_msm_slicescan, dim3((nbmax / 2u + 255u) / 256u, pl.W), dim3(256), 0, ss, hist16, ps, nslices, nbmax, base, counts);
         }
-        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk);
-        hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, s, blk, scan_blocks, pl.NB, taskoff, totals, lenhist);
-        hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, s, counts, pl.NB, lshift, blk, offsets, taskoff);
+        hipLaunchKernelGGL(k_msm_scan_sums, dim3(scan_blocks), dim3(1024), 0, ss, counts, pl.NB, lshift, blk);
+        hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, ss, blk, scan_blocks, pl.NB, taskoff, totals, lenhist);
+        hipLaunchKernelGGL(k_msm_scan_apply, dim3(scan_blocks), dim3(1024), 0, ss, counts, pl.NB, lshift, blk, offsets, taskoff);
         if (!sort2 && small_lds)
-            hipLaunchKernelGGL(k_msm_scatter<4096u>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
+            hipLaunchKernelGGL(k_msm_scatter<4096u>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, ss, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
         else if (!sort2)
-            hipLaunchKernelGGL(k_msm_scatter<kLdsWords>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, s, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
-        hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, counts, offsets, taskoff, pl.NB, lshift, tasks,
+            hipLaunchKernelGGL(k_msm_scatter<kLdsWords>, dim3(8u * nslices * (((uint32_t)pl.W + 7u) / 8u)), dim3(1024), 0, ss, digits, ps, nslices, nbmax, base, offsets, entries, scatter_passes);
+        hipLaunchKernelGGL(k_msm_tasks, dim3((pl.NB + kTaskItems - 1u) / kTaskItems), dim3(256), 0, ss, counts, offsets, taskoff, pl.NB, lshift, tasks,
                            split_small, split_big, totals + 2, lenhist, gshift, split_g, taskbkt, bacc, first_shard);
         const uint32_t task_blocks = (ps.max_tasks + 255u) / 256u;
-        hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, s, lenhist, lenoff, ranges);
-        hipLaunchKernelGGL(k_msm_task_perm, dim3((ps.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, s, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
+        hipLaunchKernelGGL(k_msm_task_scan, dim3(1), dim3(64), 0, ss, lenhist, lenoff, ranges);
+        hipLaunchKernelGGL(k_msm_task_perm, dim3((ps.max_tasks + kTaskItems - 1u) / kTaskItems), dim3(256), 0, ss, tasks, totals, lenoff, perm, gshift, (const uint32_t *)taskoff, split_g);
+        if (overlap) {
+            HIPCHK(hipEventRecord(e->ev_sorted[sh], ss));
+            HIPCHK(hipStreamWaitEvent(s, e->ev_sorted[sh], 0));
+        }
         if (last) HIPCHK(hipEventRecord(e->ev_a, s));
         if (two_level) {
             int st2 = E_SUCCESS;
@@ -2097,6 +2122,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
             launch_fold_big(s, limb_form || g2_limb, partial, taskoff, split_big, totals + 2);
             launch_reduce(s, red_blocks, four, limb_form || g2_limb, partial, taskoff, pl, rg, winout, two_level_p ? &rcp : nullptr, reinterpret_cast<Xyzz<FpL> *>(e->rcsum.p));
         }
+        if (overlap) HIPCHK(hipEventRecord(e->ev_accdone[sh], s));
     }
     HIPCHK(hipEventRecord(e->ev_stop, s));
     HIPCHK(hipGetLastError());

@@ -96,6 +96,39 @@ elif mode == "pipe":                     # ONE device.  G1 (round 4): EIP2537_H2
     th = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
     [t.start() for t in th]; [t.join() for t in th]
     assert all(r == want for r in res)
+elif mode == "dev_shards":               # ONE device, DEVICE-resident input, EIP2537_DEV_STAGES=1,2,2: three record shards of one bucket space,
+    import torch                         # the sort stage of shard s + 1 on a second stream beside the accumulate of shard s (msm.hip)
+    dev = lambda buf: torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    def dcall(buf, n):
+        d = dev(buf)
+        try: return 0, X.dev_call("eip2537_hip_g1multiexp_dev", d.data_ptr(), n)
+        except Eip2537Error as e: return e.code, None
+    n = (1 << 17) + 1
+    g1 = clib.gen_msm_input("g1", n, A, B, 4242)
+    assert dcall(g1, n) == clib.call("bls12_g1multiexp", g1)
+    assert X.last_plan()["units"] == n and X.last_plan()["shards"] == 3, X.last_plan()
+    for rep in range(3): assert dcall(g1, n) == clib.call("bls12_g1multiexp", g1)         # the doubled buffers and events are reused
+    bad = bytearray(g1); bad[120000 * 160 + 0] = 1                     # pad byte: INVALID_ELEMENT in shard 2
+    assert dcall(bytes(bad), n) == (3, None)
+    bad[10 * 160 + 16:10 * 160 + 128] = m.encode_g1((1, 1))[16:]       # (1,1) off curve in shard 0 -> wins
+    assert dcall(bytes(bad), n) == (1, None)
+    P = m.g1_mul(m.G1, 0xabcdef)
+    rec = lambda pt, k: m.encode_g1(pt) + m.encode_scalar(k)
+    body = bytearray(g1)
+    for i in range(3): body[(i * 52429 + 5) * 160:(i * 52429 + 6) * 160] = rec(P, 0x1234567)     # the same bucket in every shard
+    assert dcall(bytes(body), n) == clib.call("bls12_g1multiexp", bytes(body))
+    third = n // 5 + 7
+    canc = bytearray(g1[:third * 160]) + bytearray(len(g1) - third * 160)
+    for i in range(third, n):                                           # a later shard cancels shard 0; the rest is infinity
+        j = i - third
+        if j < third: canc[i * 160:i * 160 + 160] = g1[j * 160:j * 160 + 64] + m.encode_g1(m.ec_neg(m.FP, m.decode_g1(g1[j * 160:j * 160 + 128])))[64:] + g1[j * 160 + 128:j * 160 + 160]
+    assert dcall(bytes(canc), n) == (0, bytes(128))
+    same = b"".join(rec(P, 7) for _ in range(n))                       # degenerate input: the sort stands down, the host re-runs unsharded
+    assert dcall(same, n) == clib.call("bls12_g1multiexp", same)
+    gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
+    g20 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
+    assert dcall(g20, 1 << 20) == (0, gold("g1msm_2p20.hex"))
+    assert X.last_plan()["shards"] == 3
 elif mode == "pipe_default":             # ONE device, default policy: 2^20 G1 records staged in several shards, 2^16 = one copy
     gold = lambda name: bytes.fromhex(open(os.path.join(sys.argv[1], "tests", "golden", name)).read().strip())
     g1 = X.gen_msm_input("g1", 1 << 20, A, B, 0x25370000 + 20)
@@ -167,3 +200,7 @@ def test_callers_current_device_is_preserved(X, clib):
     assert torch.cuda.current_device() == before
     assert X.trim(0) >= 0                                  # idle slots give their workspace back
     assert X.g1_multiexp(inp) == clib.call("bls12_g1multiexp", inp)[1]
+
+
+def test_device_resident_record_shards(tmp_path, clib, X):
+    _run(tmp_path, "dev_shards", "0", {"EIP2537_DEV_STAGES": "1,2,2"})
