@@ -1671,6 +1671,50 @@ k_msm_rowcol_p(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict
     }
     if (sub == 0) rc[w * (R + C) + (is_row ? job : Rw + job)] = acc;
 }
+// The same sums with FOUR lanes per addition (add4: the four products of a round dealt over the lanes, ~1/3 of a one-lane addition's latency):
+// a 4-lane group per chain of kChain buckets (8: 1 224 waves at two per SIMD; 16: 614 waves), then the tree over the job's groups.  The
+// launch is latency-bound (7 one-lane additions in a row on 612 waves), which is what more lanes per addition shorten.
+template <uint32_t kChain>
+__global__ void __launch_bounds__(256, 2)
+k_msm_rowcol_p4(const Xyzz<Fp> *__restrict__ partial_, const uint32_t *__restrict__ taskoff, RcpGeom g, Xyzz<FpL> *__restrict__ rc) {
+    const Xyzz<FpL> *__restrict__ partial = reinterpret_cast<const Xyzz<FpL> *>(partial_);
+    const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rt = g.BT >> g.logC;
+    const uint32_t col_t = Rt >= kChain ? Rt / kChain : 1u;             // groups of a top-window column job (8 rows: one short chain)
+    const uint32_t groups_w = 2u * g.B / kChain, groups_t = Rt * (C / kChain) + C * col_t, main_total = (g.W - 1u) * groups_w;
+    const int lane = threadIdx.x & 63, r = lane & 3, gb = lane & ~3;
+    const uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 2;          // group
+    uint32_t w, local, Rw, row_groups, lj_col;
+    if (t < main_total) { w = t / groups_w; local = t % groups_w; Rw = R; row_groups = g.B / kChain; lj_col = R / kChain; }
+    else { local = t - main_total; w = g.W - 1u; Rw = Rt; row_groups = Rt * (C / kChain); lj_col = col_t; }
+    const bool live = t < main_total + groups_t;                        // (the grid's last wave: whole groups past the end)
+    const bool is_row = local < row_groups;
+    const uint32_t lj = is_row ? C / kChain : lj_col;                   // groups per job
+    const uint32_t nbj = is_row ? C : Rw, chain = nbj / lj;             // buckets per job, per group
+    const uint32_t l2 = is_row ? local : local - row_groups, job = l2 / lj, sub = l2 % lj;
+    // row job: buckets C job + (sub + i lj);   column job: buckets C (sub + i lj) + job
+    const uint32_t first = w * g.B + (is_row ? job * C + sub : sub * C + job);
+    const uint32_t step = is_row ? lj : lj * C;
+    auto fetch = [&](uint32_t i) {
+        const uint32_t b = first + i * step, t0 = taskoff[b], t1 = taskoff[b + 1];
+        return t1 > t0 ? partial[t0] : xyzz_inf<FpL>();                // multi-task buckets were folded into slot t0
+    };
+    Xyzz<FpL> acc = xyzz_inf<FpL>();
+    if (live) {                                                         // uniform in the group
+        acc = fetch(0);
+        Xyzz<FpL> nxt = chain > 1u ? fetch(1) : xyzz_inf<FpL>();
+#pragma unroll 1
+        for (uint32_t i = 1; i < chain; i++) {
+            const Xyzz<FpL> cur = nxt;
+            if (i + 1 < chain) nxt = fetch(i + 1);                      // in flight during the addition below
+            acc = add4(acc, cur, r, gb);
+        }
+    }
+    for (uint32_t off = (C / kChain) >> 1; off >= 1; off >>= 1) {       // a job's groups are one aligned run of the wave; column jobs have fewer
+        const Xyzz<FpL> o = shfl_from(acc, (lane + 4 * (int)off) & 63);
+        if (live && off < lj && sub < off) acc = add4(acc, o, r, gb);
+    }
+    if (live && sub == 0 && r == 0) rc[w * (R + C) + (is_row ? job : Rw + job)] = acc;
+}
 // grid = 2 W blocks: block 2 w sums hi Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of window w; 64 four-lane groups, one entry each
 __global__ void __launch_bounds__(256, 1)
 k_msm_reduce_rc_p(const Xyzz<FpL> *__restrict__ rc, RcpGeom g, Xyzz<Fp> *__restrict__ winout) {
@@ -1741,8 +1785,19 @@ static void launch_fold_big(hipStream_t s, bool limb, Xyzz<Fp2> *partial, const 
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool limb, const Xyzz<Fp> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp> *winout, const RcpGeom *rcp, Xyzz<FpL> *rc) {
     if (rcp) {                  // c = 13: row / column sums, then the weighted sums (two launches; red_blocks = 2 W)
-        const uint32_t lanes = (rcp->W - 1u) * (2u * rcp->B / kRcpChain) + 2u * rcp->BT / kRcpChain;
-        hipLaunchKernelGGL(k_msm_rowcol_p, dim3((lanes + 255u) / 256u), dim3(256), 0, s, partial, taskoff, *rcp, rc);
+        // EIP2537_RCP_CHAIN=4: one lane per chain of 4 buckets (k_msm_rowcol_p); 8 | 16: a 4-lane group per chain (k_msm_rowcol_p4)
+        static const uint32_t env_chain = [] { const char *v = getenv("EIP2537_RCP_CHAIN"); return v ? (uint32_t)atoi(v) : 0u; }();
+        const uint32_t chain = env_chain == 4u || env_chain == 8u || env_chain == 16u ? env_chain : 8u;
+        const uint32_t C = 1u << rcp->logC, Rt = rcp->BT >> rcp->logC;
+        if (chain == 4u) {
+            const uint32_t lanes = (rcp->W - 1u) * (2u * rcp->B / kRcpChain) + 2u * rcp->BT / kRcpChain;
+            hipLaunchKernelGGL(k_msm_rowcol_p, dim3((lanes + 255u) / 256u), dim3(256), 0, s, partial, taskoff, *rcp, rc);
+        } else {
+            const uint32_t groups = (rcp->W - 1u) * (2u * rcp->B / chain) + Rt * (C / chain) + C * (Rt >= chain ? Rt / chain : 1u);
+            const dim3 grid((groups * 4u + 255u) / 256u);
+            if (chain == 8u) hipLaunchKernelGGL(k_msm_rowcol_p4<8u>, grid, dim3(256), 0, s, partial, taskoff, *rcp, rc);
+            else hipLaunchKernelGGL(k_msm_rowcol_p4<16u>, grid, dim3(256), 0, s, partial, taskoff, *rcp, rc);
+        }
         hipLaunchKernelGGL(k_msm_reduce_rc_p, dim3(red_blocks), dim3(256), 0, s, (const Xyzz<FpL> *)rc, *rcp, winout);
         return;
     }
