@@ -1741,6 +1741,70 @@ k_msm_reduce_rc_p(const Xyzz<FpL> *__restrict__ rc, RcpGeom g, Xyzz<Fp> *__restr
     }
 }
 
+// ---- the same two-level split for G2 at c = 13 (BASELINE config 3), on 8-lane groups in limb form (g2_limb.h) ---------------------------
+// k_msm_reduce8c_l is one chain of 2 S + ~13 (offset multiple) + 6 (trees) additions of ~12 us per segment, plus a wave per window
+// (k_msm_window_sum8c_l) for the block sums.  Rows and columns: k_msm_rowcol8_p gives every job (a row or a column of 64 buckets; the
+// top window: 8 rows, columns of 8) four 8-lane groups -- 15 additions and a 2-level tree, 1 228 waves at two per SIMD -- and
+// k_msm_reduce_rc8_p one block per (window, kind): group j takes the entries 2 j, 2 j + 1 as  (2 j + kind) (E0 + E1) + E1, then the block tree,
+// and leaves the canonical point the host reads (two per window).
+__global__ void __launch_bounds__(256, 2)
+k_msm_rowcol8_p(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, RcpGeom g, Pt2L *__restrict__ rc) {
+    constexpr uint32_t kChain = 16;
+    const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rt = g.BT >> g.logC;
+    const uint32_t col_t = Rt >= kChain ? Rt / kChain : 1u;
+    const uint32_t groups_w = 2u * g.B / kChain, groups_t = Rt * (C / kChain) + C * col_t, main_total = (g.W - 1u) * groups_w;
+    const int lane = threadIdx.x & 63, sl = lane & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    const uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 3;          // group
+    uint32_t w, local, Rw, row_groups, lj_col;
+    if (t < main_total) { w = t / groups_w; local = t % groups_w; Rw = R; row_groups = g.B / kChain; lj_col = R / kChain; }
+    else { local = t - main_total; w = g.W - 1u; Rw = Rt; row_groups = Rt * (C / kChain); lj_col = col_t; }
+    const bool live = t < main_total + groups_t;
+    const bool is_row = local < row_groups;
+    const uint32_t lj = is_row ? C / kChain : lj_col;                   // groups per job
+    const uint32_t nbj = is_row ? C : Rw, chain = nbj / lj;
+    const uint32_t l2 = is_row ? local : local - row_groups, job = l2 / lj, sub = l2 % lj;
+    const uint32_t first = w * g.B + (is_row ? job * C + sub : sub * C + job);
+    const uint32_t step = is_row ? lj : lj * C;
+    auto fetch = [&](uint32_t i) {
+        const uint32_t b = first + i * step, t0 = taskoff[b], t1 = taskoff[b + 1];
+        return t1 > t0 ? load_pt2l(&partial[t0], x.q) : xyzzk_inf<1>();  // multi-task buckets were folded into slot t0
+    };
+    XyzzK<1> acc = xyzzk_inf<1>();
+    if (live) {                                                         // uniform in the group
+        acc = fetch(0);
+#pragma unroll 1
+        for (uint32_t i = 1; i < chain; i++) acc = add8k(x, acc, fetch(i));      // (no prefetch: the next point's 52 registers are the difference
+    }                                                                            //  between two waves per SIMD and spills; the other wave hides the load)
+    for (uint32_t off = (C / kChain) >> 1; off >= 1; off >>= 1) {       // a job's groups are one aligned run of the wave
+        const XyzzK<1> o = shfl_from(acc, (lane + 8 * (int)off) & 63);
+        if (live && off < lj && sub < off) acc = add8k(x, acc, o);
+    }
+    if (live && sub == 0 && sl < 2) store_pt2l(&rc[w * (R + C) + (is_row ? job : Rw + job)], acc, x.q);
+}
+// grid = 2 W blocks: block 2 w sums hi Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of window w; 32 eight-lane groups, two entries each
+__global__ void __launch_bounds__(256)
+k_msm_reduce_rc8_p(const Pt2L *__restrict__ rc, RcpGeom g, Xyzz<Fp2> *__restrict__ winout) {
+    __shared__ BlockSum8k sm;
+    const uint32_t w = blockIdx.x >> 1, kind = blockIdx.x & 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rw = w == g.W - 1u ? g.BT >> g.logC : R;
+    const uint32_t n = kind ? C : Rw, e0 = 2u * (uint32_t)(threadIdx.x >> 3);      // entries e0, e0 + 1 of this group (n even, <= 64)
+    const Pt2L *ent = rc + (size_t)w * (R + C) + (kind ? Rw : 0u);
+    XyzzK<1> Cs = xyzzk_inf<1>();
+    if (e0 < n) {                                                       // uniform in the group
+        const XyzzK<1> E0 = load_pt2l(&ent[e0], x.q), E1 = load_pt2l(&ent[e0 + 1u], x.q);
+        // weights e (rows) | e + 1 (columns):  (e0 + kind) E0 + (e0 + kind + 1) E1 = (e0 + kind) (E0 + E1) + E1
+        Cs = add8k(x, small_mul8k(x, add8k(x, E0, E1), e0 + kind), E1);
+    }
+    Cs = block_sum8k(x, Cs, sm, lane, wave);
+    if (threadIdx.x < 2) {
+        const Xyzz<FpI> out{to_fpi(Cs.x.l[0]), to_fpi(Cs.y.l[0]), to_fpi(Cs.zz.l[0]), to_fpi(Cs.zzz.l[0])};
+        store_component(&winout[blockIdx.x], out, x.q);
+    }
+}
+
 static void launch_accum(hipStream_t s, uint32_t task_blocks, bool chain_bound, const Aff<Fp> *pts, const void *limb_recs, const uint32_t *entries,
                          const Task *tasks, const uint32_t *perm, const uint32_t *totals, Xyzz<Fp> *partial) {
     const PtL *ptl = reinterpret_cast<const PtL *>(limb_recs);
@@ -1807,7 +1871,15 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool li
     else hipLaunchKernelGGL(k_msm_reduce1<Fp>, dim3(red_blocks), dim3(256), 0, s, partial, taskoff, pl, rg, winout);
 }
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool limb, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
-                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout, const RcpGeom *, Xyzz<FpL> *) {
+                          const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout, const RcpGeom *rcp, Xyzz<FpL> *rc) {
+    if (rcp) {                  // c = 13, limb form: row / column sums, then the weighted sums (red_blocks = 2 W canonical points)
+        const uint32_t C = 1u << rcp->logC, Rt = rcp->BT >> rcp->logC;
+        const uint32_t groups = (rcp->W - 1u) * (2u * rcp->B / 16u) + Rt * (C / 16u) + C;
+        Pt2L *rc8 = reinterpret_cast<Pt2L *>(rc);
+        hipLaunchKernelGGL(k_msm_rowcol8_p, dim3((groups * 8u + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const Pt2L *>(partial), taskoff, *rcp, rc8);
+        hipLaunchKernelGGL(k_msm_reduce_rc8_p, dim3(red_blocks), dim3(256), 0, s, (const Pt2L *)rc8, *rcp, winout);
+        return;
+    }
     if (limb) {                 // limb-form block sums live behind the W canonical window sums
         Pt2L *blkout = reinterpret_cast<Pt2L *>(winout + red_blocks + pl.W);
         hipLaunchKernelGGL(k_msm_reduce8c_l, dim3(red_blocks), dim3(256), 0, s, reinterpret_cast<const Pt2L *>(partial), taskoff, pl, rg, blkout);
@@ -1952,9 +2024,15 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // the 4-lane running-sum chain k_msm_reduce4
     static const bool env_rcp = [] { const char *v = getenv("EIP2537_REDUCE_RCP"); return !v || atoi(v) != 0; }();
     const RcpGeom rcp{pl.B, pl.BT, 6u, (uint32_t)pl.W};
-    const bool two_level_p = !two_level && limb_form && four && env_rcp && !ReduceCfg<F>::kFourLane && pl.c == 13 && pl.B == 4096u && pl.BT == 512u;
+    // G2: accumulate, fold and reduce in limb form too (k_msm_accum2c_l, g2_limb.h); EIP2537_G2_LIMB=0: the FpI kernels
+    static const bool env_g2limb = [] { const char *v = getenv("EIP2537_G2_LIMB"); return !v || atoi(v) != 0; }();
+    const bool g2_limb = ReduceCfg<F>::kFourLane && env_g2limb;
+    // G2, c = 13: k_msm_rowcol8_p / k_msm_reduce_rc8_p; EIP2537_REDUCE_RCP8=0: the running-sum chain k_msm_reduce8c_l
+    static const bool env_rcp8 = [] { const char *v = getenv("EIP2537_REDUCE_RCP8"); return !v || atoi(v) != 0; }();
+    const bool two_level_p = !two_level && pl.c == 13 && pl.B == 4096u && pl.BT == 512u &&
+                             (ReduceCfg<F>::kFourLane ? (g2_limb && env_rcp8) : (limb_form && four && env_rcp));
     if (two_level_p) red_blocks = 2u * (uint32_t)pl.W;
-    const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level;      // G2: one sum per window comes back, not one per block
+    const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level && !two_level_p;      // G2: one sum per window comes back, not one per block
     const size_t nwin_out = dev_winsum ? (size_t)pl.W : red_blocks;
     const size_t rc_bytes = two_level ? (size_t)(pl.W + 1) * kRcPerWindow * sizeof(Xyzz<FpL>) : 0;
     const uint32_t split_top = two_level ? (uint32_t)pl.W * pl.B : 0xffffffffu;      // first bucket of the top window's upper half
@@ -1989,9 +2067,6 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     }
     pl.L = 1u << shift_for(ns_max);
     pl.max_tasks = max_tasks;
-    // G2: the accumulate in limb form too (k_msm_accum2c_l; fold and reduce stay in FpI words); EIP2537_G2_LIMB=0: k_msm_accum2c
-    static const bool env_g2limb = [] { const char *v = getenv("EIP2537_G2_LIMB"); return !v || atoi(v) != 0; }();
-    const bool g2_limb = ReduceCfg<F>::kFourLane && env_g2limb;
     // Sharded call: the SORT stage of shard s + 1 (decode .. task order: latency- and LDS-bound kernels that leave the vector units idle)
     // runs on stream3 beside the ACCUMULATE of shard s on the main stream.  Everything the accumulate / fold kernels read from the sort
     // stage exists twice (by shard parity); events order sort(s) -> accumulate(s) and accumulate(s) -> sort(s + 2).
@@ -2028,7 +2103,7 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->scan_blk.reserve(dup * kScanBlkWords * 4));   // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
     HIPCHK(e->perm.reserve(dup * (size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve(dup * (size_t)pl.NB * 8));      // split-bucket lists: small | big
-    if (two_level_p) HIPCHK(e->rcsum.reserve((size_t)pl.W * 128u * sizeof(Xyzz<FpL>)));      // per window: 64 row + 64 column sums
+    if (two_level_p) HIPCHK(e->rcsum.reserve((size_t)pl.W * 128u * (g2_limb ? sizeof(Pt2L) : sizeof(Xyzz<FpL>))));      // per window: 64 row + 64 column sums
     if (two_level) {
         HIPCHK(e->bacc.reserve((size_t)pl.NB * sizeof(Xyzz<FpL>)));
         HIPCHK(e->taskbkt.reserve(dup * (size_t)pl.max_tasks * 4));
