@@ -2,11 +2,13 @@
 # Refresh the round-4 measurement artefacts (GPU box, repo root).  Part 1: per-kernel profiles with PMC passes, the traffic json
 # bench.py quotes, the three bench lines.  Part 2 (tools/refresh_r04.sh part2): size sweep, native concurrent callers against the
 # round-2 library, in-library split on one GPU, degenerate inputs, the 4-rank rehearsal, the long fuzz.
+# part3: the size sweep, host-ABI sizes and degenerate inputs of part 2 only.
 # Results land in gpurun_out/final4/; copy into profiles/ to commit.
 export GPU_MAX_HW_QUEUES=16
 O=gpurun_out/final4; mkdir -p $O
+MODE=$1
 step() { echo "== $* ($(date +%T))" | tee -a $O/progress.log; }
-if [ "$1" != "part2" ]; then
+if [ "$MODE" != "part2" ] && [ "$MODE" != "part3" ]; then
 step prof g1msm 2^20;  timeout -k 10 500 bash tools/prof_kernels.sh r04_g1msm_2p20 --steps 5 --warmup 2 --no-secondary > $O/prof_g1_20.log 2>&1 || exit 1
 step prof pairing;     timeout -k 10 400 bash tools/prof_kernels.sh r04_pairing_2p12 --workload pairing --steps 10 --warmup 2 > $O/prof_pair.log 2>&1 || exit 1
 step prof g2msm 2^16;  timeout -k 10 400 bash tools/prof_kernels.sh r04_g2msm_2p16 --workload g2msm --steps 10 --warmup 2 > $O/prof_g2.log 2>&1 || exit 1
@@ -30,6 +32,7 @@ step host-ABI sizes
 for l in 18 19 20 21 22; do timeout -k 10 200 python tools/dbg_host_abi.py $l g1 2>&1 | grep -v amdgpu.ids | tee -a $O/r04_host_abi_sizes.txt; done
 EIP2537_H2D_PIPELINE=0 timeout -k 10 200 python tools/dbg_host_abi.py 20 g1 2>&1 | grep -v amdgpu.ids | tee -a $O/r04_host_abi_sizes.txt
 timeout -k 10 200 python tools/dbg_host_abi.py 18 g2 2>&1 | grep -v amdgpu.ids | tee -a $O/r04_host_abi_sizes.txt
+[ "$MODE" = "part3" ] && { step degenerate; timeout -k 10 300 python tools/degenerate_timing.py 2>&1 | grep -v amdgpu.ids > $O/r04_degenerate_inputs.txt; step part 3 done; exit 0; }
 step in-library split, one GPU
 for dv in "0,0" "0,0,0,0"; do
   echo "EIP2537_HIP_DEVICES=$dv" | tee -a $O/r04_in_library_split.txt
