@@ -27,6 +27,7 @@
 #include "codec.h"
 #include "pairing.h"
 #include "ifma.h"
+#include "ifma_horner.h"
 #include "h2c.h"
 #include "limbk.h"
 #include "engine.h"
@@ -628,7 +629,7 @@ template <class F> static int msm_coalesced(byte *out, const byte *in, size_t n)
     } else {                            // Horner over the 32 window sums, highest window first
         acc = xyzz_inf<F>();
         for (int w = kMsmBatchWindows - 1; w >= 0; w--) {
-            for (int d = 0; d < kMsmBatchWindowBits; d++) acc = dbl(acc);
+            horner_double_n(acc, kMsmBatchWindowBits);
             acc = add(acc, req.wins[w]);
         }
     }

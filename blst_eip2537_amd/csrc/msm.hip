@@ -28,6 +28,7 @@
 #include "limb30.h"
 #include "dev_lanes.h"
 #include "g2_limb.h"
+#include "ifma_horner.h"
 #include "engine.h"
 
 namespace eip {
@@ -2291,25 +2292,25 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         hw[3 * (size_t)(pl.W - 1) + 1] = add(hw[3 * (size_t)(pl.W - 1) + 1], hw[3 * (size_t)pl.W + 1]);
         for (int w = pl.W - 1; w >= 0; w--)
             for (int h = 0; h < 2; h++) {
-                for (int d = 0; d < pl.c / 2; d++) acc = dbl(acc);
+                horner_double_n(acc, pl.c / 2);
                 acc = add(acc, hw[3 * w + h]);
             }
     } else if (two_level_p) {
         // window sum = 64 R_w + C_w: a 7-bit and a 6-bit half-window
         for (int w = pl.W - 1; w >= 0; w--) {
-            for (int d = 0; d < pl.c - (int)rcp.logC; d++) acc = dbl(acc);
+            horner_double_n(acc, pl.c - (int)rcp.logC);
             acc = add(acc, hw[2 * (size_t)w]);
-            for (int d = 0; d < (int)rcp.logC; d++) acc = dbl(acc);
+            horner_double_n(acc, (int)rcp.logC);
             acc = add(acc, hw[2 * (size_t)w + 1]);
         }
     } else if (dev_winsum) {
         for (int w = pl.W - 1; w >= 0; w--) {
-            for (int d = 0; d < pl.c; d++) acc = dbl(acc);
+            horner_double_n(acc, pl.c);
             acc = add(acc, hw[(size_t)w]);
         }
     } else
     for (int w = pl.W - 1; w >= 0; w--) {
-        for (int d = 0; d < pl.c; d++) acc = dbl(acc);
+        horner_double_n(acc, pl.c);
         const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
         for (uint32_t b = 0; b < nb; b++) acc = add(acc, hw[b0 + b]);
     }

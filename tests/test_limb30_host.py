@@ -52,8 +52,9 @@ def test_host_ifma_arithmetic_matches_scalar(tmp_path):
     assert out.returncode == 0, out.stdout
     if "skipped" in out.stdout:
         pytest.skip("no AVX-512 IFMA on this CPU")
+    # "multiexp doubling chains": csrc/ifma_horner.h, the Horner doublings of a multiexp's host tail (G1 and G2) against curve.h
     for part in ("vector field operations", "cyclotomic squaring chains", "Fp12 products",
-                 "exponentiation by z, final exponentiation, Horner"):
+                 "exponentiation by z, final exponentiation, Horner", "multiexp doubling chains"):
         assert part + ": 0 mismatches" in out.stdout, out.stdout
 
 

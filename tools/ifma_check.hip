@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include "pairing.h"
 #include "ifma.h"
+#include "h2c.h"
+#include "ifma_horner.h"
 using namespace eip;
 static uint64_t g_s = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() { g_s ^= g_s << 13; g_s ^= g_s >> 7; g_s ^= g_s << 17; return g_s; }
@@ -87,6 +89,80 @@ __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl,avx512bw"))) static 
         if (!eq(horner_groups_ifma(L, sq, 17), want)) bad4++;
     }
     printf("exponentiation by z, final exponentiation, Horner: %ld mismatches\n", bad4);
+    // ---- doubling chains of the multiexp host tail (ifma_horner.h) against curve.h ----
+    long bad5 = 0;
+    {
+        const Aff<Fp> g1{Fp{{K_G1_X}}, Fp{{K_G1_Y}}};
+        const Aff<Fp2> g2{Fp2{Fp{{K_G2_X_C0}}, Fp{{K_G2_X_C1}}}, Fp2{Fp{{K_G2_Y_C0}}, Fp{{K_G2_Y_C1}}}};
+        auto same1 = [](const Xyzz<Fp> &a, const Xyzz<Fp> &b) {
+            if (is_zero(a.zz) || is_zero(b.zz)) return is_zero(a.zz) && is_zero(b.zz);
+            const Aff<Fp> x = to_affine(a), y = to_affine(b);
+            return eq(x.x, y.x) && eq(x.y, y.y);
+        };
+        auto same2 = [](const Xyzz<Fp2> &a, const Xyzz<Fp2> &b) {
+            if (is_zero(a.zz) || is_zero(b.zz)) return is_zero(a.zz) && is_zero(b.zz);
+            const Aff<Fp2> x = to_affine(a), y = to_affine(b);
+            return eq(x.x, y.x) && eq(x.y, y.y);
+        };
+        for (int it = 0; it < 200; it++) {
+            uint32_t k[8];
+            for (auto &w : k) w = (uint32_t)rnd();
+            // a random XYZZ representative of a random multiple (every fifth: a curve point outside the subgroup)
+            Xyzz<Fp> p1 = scalar_mul(g1, k, 256);
+            Xyzz<Fp2> p2 = scalar_mul(g2, k, 256);
+            if (it % 5 == 4) {
+                const Aff<Fp> c1 = map_to_curve<Fp>(rnd_fp());
+                const Aff<Fp2> c2 = map_to_curve<Fp2>(r2());
+                p1 = Xyzz<Fp>{c1.x, c1.y, fp_one(), fp_one()};
+                p2 = Xyzz<Fp2>{c2.x, c2.y, fp2_one(), fp2_one()};
+            }
+            const int n = 1 + (int)(rnd() % 17);
+            Xyzz<Fp> w1 = p1, v1 = p1;
+            Xyzz<Fp2> w2 = p2, v2 = p2;
+            for (int i = 0; i < n; i++) { w1 = dbl(w1); w2 = dbl(w2); }
+            double_n(v1, n);
+            double_n(v2, n);
+            if (!same1(v1, w1)) bad5++;
+            if (!same2(v2, w2)) bad5++;
+            // a whole Horner pass: 16 windows of 16 doublings with an addition between them
+            if (it < 20) {
+                Xyzz<Fp> a1 = xyzz_inf<Fp>(), b1 = a1;
+                Xyzz<Fp2> a2 = xyzz_inf<Fp2>(), b2 = a2;
+                for (int w = 0; w < 16; w++) {
+                    for (int i = 0; i < 16; i++) { a1 = dbl(a1); a2 = dbl(a2); }
+                    horner_double_n(b1, 16);
+                    horner_double_n(b2, 16);
+                    if (w % 5 != 3) { a1 = add(a1, p1); b1 = add(b1, p1); a2 = add(a2, p2); b2 = add(b2, p2); }
+                }
+                if (!same1(a1, b1) || !same2(a2, b2)) bad5++;
+            }
+        }
+        Xyzz<Fp2> i2 = xyzz_inf<Fp2>();
+        double_n(i2, 5);                                       // infinity stays infinity through the vectors too
+        if (!is_zero(i2.zz)) bad5++;
+        Xyzz<Fp> i1 = xyzz_inf<Fp>();
+        double_n(i1, 5);
+        if (!is_zero(i1.zz)) bad5++;
+    }
+    printf("multiexp doubling chains: %ld mismatches\n", bad5);
+    {
+        const Aff<Fp> g1{Fp{{K_G1_X}}, Fp{{K_G1_Y}}};
+        const Aff<Fp2> g2{Fp2{Fp{{K_G2_X_C0}}, Fp{{K_G2_X_C1}}}, Fp2{Fp{{K_G2_Y_C0}}, Fp{{K_G2_Y_C1}}}};
+        Xyzz<Fp> a1{g1.x, g1.y, fp_one(), fp_one()}, b1 = a1;
+        Xyzz<Fp2> a2{g2.x, g2.y, fp2_one(), fp2_one()}, b2 = a2;
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 2560; i++) a1 = dbl(a1);
+        auto t1 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 160; i++) double_n(b1, 16);
+        auto t2 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 2560; i++) a2 = dbl(a2);
+        auto t3 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 160; i++) double_n(b2, 16);
+        auto t4 = std::chrono::steady_clock::now();
+        printf("doubling (chains of 16, conversions included): G1 scalar %.3f us, ifma %.3f us; G2 scalar %.3f us, ifma %.3f us (%d)\n", us(t0, t1) / 2560, us(t1, t2) / 2560,
+               us(t2, t3) / 2560, us(t3, t4) / 2560, (int)((a1.x.l[0] ^ b1.x.l[0] ^ a2.x.c0.l[0] ^ b2.x.c0.l[0]) & 1));
+    }
     // timing
     Fp12 f = r12();
     auto t0 = std::chrono::steady_clock::now();
@@ -105,7 +181,7 @@ __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl,avx512bw"))) static 
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     printf("final_exp: scalar %.1f us, ifma %.1f us (%s); vector Fp12 product %.3f us, cyclotomic squaring %.3f us (%d)\n", us(t0, t1) / 50, us(t1, t2) / 50,
            eq(x, y) ? "equal" : "DIFFERENT", us(t2, t3) / 2000, us(t3, t4) / 2000, (int)(_mm512_reduce_add_epi64(v.c0.l[0]) + _mm512_reduce_add_epi64(c.c0.l[0])) & 1);
-    return (bad || bad2 || bad3 || bad4 || !eq(x, y)) ? 1 : 0;
+    return (bad || bad2 || bad3 || bad4 || bad5 || !eq(x, y)) ? 1 : 0;
 }
 #else
 static int run() { return 0; }
