@@ -335,7 +335,9 @@ template <class F> static int host_mul(byte *out, const byte *in, size_t in_len)
     uint32_t sw[8], k[8];
     memcpy(sw, in + pb, 32);
     decode_scalar(k, sw);
-    host_encode_point<F>(out, to_affine(scalar_mul(a, k, 256)));
+    // G2: the windowed form (260 doublings in chains of 5 on IFMA vectors + 52 additions) instead of 256 doublings + ~128 mixed additions
+    if (std::is_same<F, Fp2>::value) host_encode_point<F>(out, to_affine(msm_interleaved<F>(&a, k, 1)));
+    else host_encode_point<F>(out, to_affine(scalar_mul(a, k, 256)));
     return E_SUCCESS;
 }
 
@@ -1076,7 +1078,8 @@ API EIP2537_ERROR bls12_map_fp2_to_g2(byte out[256], const byte in[128], size_t 
     Fp2 u;
     if (fp_decode(u, w) < 0) return EIP2537_INVALID_ELEMENT;
     Aff<Fp2> q = map_to_curve<Fp2>(u);
-    host_encode_point<Fp2>(out, to_affine(scalar_mul(q, K_ISO_H_EFF_G2, K_ISO_H_EFF_G2_BITS)));   // h2 (3 z^2 - 3)
+    static_assert(K_ISO_H_EFF_G2_BITS <= 32 * 20, "cofactor words");
+    host_encode_point<Fp2>(out, to_affine(msm_interleaved<Fp2>(&q, K_ISO_H_EFF_G2, 1, 20)));    // h2 (3 z^2 - 3): 636 bits, signed 5-bit windows
     return EIP2537_SUCCESS;
 }
 

@@ -162,21 +162,26 @@ HD bool in_g2(const Aff<Fp2> &a) {
     return eq_affine(t, psi_neg);
 }
 
+// n doublings in a row of a host accumulator: AVX-512 IFMA vectors where they pay (ifma_horner.h, which every host translation unit
+// that calls msm_interleaved() includes), the loop over dbl() otherwise
+template <class F> inline void horner_double_n(Xyzz<F> &acc, int n);
 // sum k_i P_i for a few points on the host: interleaved signed 5-bit windows (Straus).  k: n x 8 little-endian
 // words (256-bit, NOT reduced: the points need not lie in the prime-order subgroup).  Signed digits in
 // [-15, 16] with k = sum d_w 32^w over 52 windows (the last one takes the final carry), a table of the
 // multiples 1 .. 16 per point, one chain of 5 doublings per window shared by all points.
-template <class F> inline Xyzz<F> msm_interleaved(const Aff<F> *pts, const uint32_t *k, size_t n) {
-    constexpr int kW = 5, kWindows = 52, kTable = 1 << (kW - 1);
+// nwords: 32-bit words per scalar (8: the 256-bit scalars of the precompiles; the 636-bit cofactor of the G2 map takes 20).
+template <class F> inline Xyzz<F> msm_interleaved(const Aff<F> *pts, const uint32_t *k, size_t n, int nwords = 8) {
+    constexpr int kW = 5, kTable = 1 << (kW - 1);
+    const int kWindows = (32 * nwords + kW) / kW;             // one more than the bits need: the last window takes the final carry
     Xyzz<F> *table = new Xyzz<F>[n * kTable];
     signed char *digits = new signed char[n * kWindows];
     for (size_t i = 0; i < n; i++) {
-        const uint32_t *ki = k + i * 8;
+        const uint32_t *ki = k + i * (size_t)nwords;
         int carry = 0;
         for (int w = 0; w < kWindows; w++) {
             const int bit = w * kW, word = bit >> 5, sh = bit & 31;
-            uint32_t v = word < 8 ? ki[word] >> sh : 0u;
-            if (sh > 32 - kW && word + 1 < 8) v |= ki[word + 1] << (32 - sh);
+            uint32_t v = word < nwords ? ki[word] >> sh : 0u;
+            if (sh > 32 - kW && word + 1 < nwords) v |= ki[word + 1] << (32 - sh);
             int d = (int)(v & ((1u << kW) - 1u)) + carry;
             carry = d > kTable;
             if (carry) d -= 1 << kW;
@@ -189,8 +194,7 @@ template <class F> inline Xyzz<F> msm_interleaved(const Aff<F> *pts, const uint3
     }
     Xyzz<F> acc = xyzz_inf<F>();
     for (int w = kWindows - 1; w >= 0; w--) {
-        if (!is_inf(acc))
-            for (int d = 0; d < kW; d++) acc = dbl(acc);
+        if (!is_inf(acc)) horner_double_n(acc, kW);
         for (size_t i = 0; i < n; i++) {
             const int d = digits[i * kWindows + w];
             if (d > 0) acc = add(acc, table[i * kTable + d - 1]);
