@@ -15,6 +15,8 @@ from blst_eip2537_amd import Eip2537Executor as X, Eip2537Error  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=12)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--dev", action="store_true", help="device-resident input (eip2537_hip_g1multiexp_dev): the record shards of EIP2537_DEV_STAGES, "
+                "sort stage of shard s + 1 beside the accumulate of shard s")
 args = ap.parse_args()
 rng = random.Random(args.seed)
 A, B = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6, 0x0123456789abcdef0fedcba987654321
@@ -22,6 +24,10 @@ A, B = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8ea1c3e5a7092b4d6f80a2c4e6, 0x012345678
 
 def call(inp):
     try:
+        if args.dev:
+            import torch
+            d = torch.frombuffer(bytearray(inp), dtype=torch.uint8).cuda()
+            return 0, X.dev_call("eip2537_hip_g1multiexp_dev", d.data_ptr(), len(inp) // 160)
         return 0, X.g1_multiexp(inp)
     except Eip2537Error as e:
         return e.code, None
@@ -61,5 +67,6 @@ for case in range(args.cases):
     ok = got == want
     bad += 0 if ok else 1
     print("case %2d n=%d shards=%s rc=%d %s (%.0f s)" % (case, n, (X.last_plan() or {}).get("shards"), want[0], "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
-print("fuzz_staged: %d cases, EIP2537_H2D_STAGES=%s, MISMATCHES: %d" % (args.cases, os.environ.get("EIP2537_H2D_STAGES"), bad))
+print("fuzz_staged: %d cases, %s, MISMATCHES: %d" % (args.cases, ("EIP2537_DEV_STAGES=%s (device-resident)" % os.environ.get("EIP2537_DEV_STAGES")) if args.dev
+      else "EIP2537_H2D_STAGES=%s" % os.environ.get("EIP2537_H2D_STAGES"), bad))
 sys.exit(1 if bad else 0)
