@@ -493,7 +493,7 @@ static int pairing_host_small(byte *out, const byte *in, size_t k) {
         if (!in_g1(P[i])) return E_NOT_IN_SUBGROUP;
         st = host_decode_point<Fp2>(Q[i], in + 128);
         if (st) return st;
-        if (!in_g2(Q[i])) return E_NOT_IN_SUBGROUP;
+        if (!in_g2_host(Q[i])) return E_NOT_IN_SUBGROUP;
     }
     pairing_finish(out, miller_loop_multi(P, Q, k));          // one chain of squarings for all pairs
     return E_SUCCESS;

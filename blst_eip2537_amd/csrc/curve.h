@@ -165,6 +165,22 @@ HD bool in_g2(const Aff<Fp2> &a) {
 // n doublings in a row of a host accumulator: AVX-512 IFMA vectors where they pay (ifma_horner.h, which every host translation unit
 // that calls msm_interleaved() includes), the loop over dbl() otherwise
 template <class F> inline void horner_double_n(Xyzz<F> &acc, int n);
+// in_g2() for the host route of small pairing checks: the same test, the runs of doublings of |z| as chains (63 doublings in six runs)
+inline bool in_g2_host(const Aff<Fp2> &a) {
+    if (is_inf(a)) return true;
+    Xyzz<Fp2> t = from_affine(a);
+    static_assert(K_Z_ABS == ((1ull << 63) | (1ull << 62) | (1ull << 60) | (1ull << 57) | (1ull << 48) | (1ull << 16)), "bits of |z|");
+    int prev = 63;
+    for (int bit : {62, 60, 57, 48, 16}) {
+        horner_double_n(t, prev - bit);
+        t = madd(t, a);
+        prev = bit;
+    }
+    horner_double_n(t, prev);
+    Aff<Fp2> psi_neg{mul(conj(a.x), Fp2{Fp{{K_PSI_X_C0}}, Fp{{K_PSI_X_C1}}}),
+                     neg(mul(conj(a.y), Fp2{Fp{{K_PSI_Y_C0}}, Fp{{K_PSI_Y_C1}}}))};
+    return eq_affine(t, psi_neg);
+}
 // sum k_i P_i for a few points on the host: interleaved signed 5-bit windows (Straus).  k: n x 8 little-endian
 // words (256-bit, NOT reduced: the points need not lie in the prime-order subgroup).  Signed digits in
 // [-15, 16] with k = sum d_w 32^w over 52 windows (the last one takes the final carry), a table of the
