@@ -1748,40 +1748,55 @@ k_msm_reduce_rc_p(const Xyzz<FpL> *__restrict__ rc, RcpGeom g, Xyzz<Fp> *__restr
 // top window: 8 rows, columns of 8) four 8-lane groups -- 15 additions and a 2-level tree, 1 228 waves at two per SIMD -- and
 // k_msm_reduce_rc8_p one block per (window, kind): group j takes the entries 2 j, 2 j + 1 as  (2 j + kind) (E0 + E1) + E1, then the block tree,
 // and leaves the canonical point the host reads (two per window).
-__global__ void __launch_bounds__(256, 2)
-k_msm_rowcol8_p(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, RcpGeom g, Pt2L *__restrict__ rc) {
+struct Rc8Job { uint32_t first, step, chain, lj, sub, out; bool live; };
+// group t of k_msm_rowcol8_p -> its chain of buckets and, for the job's first group, the slot of the sum (computed twice -- before the chain
+// and again for the store -- so that none of it stays in registers across the additions: the kernel sits at the 256-register line)
+__device__ __forceinline__ Rc8Job rc8_job(uint32_t t, const RcpGeom &g) {
     constexpr uint32_t kChain = 16;
     const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rt = g.BT >> g.logC;
     const uint32_t col_t = Rt >= kChain ? Rt / kChain : 1u;
     const uint32_t groups_w = 2u * g.B / kChain, groups_t = Rt * (C / kChain) + C * col_t, main_total = (g.W - 1u) * groups_w;
-    const int lane = threadIdx.x & 63, sl = lane & 7;
-    const DevLanes8 x{sl >> 1, sl & 1};
-    const uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 3;          // group
     uint32_t w, local, Rw, row_groups, lj_col;
     if (t < main_total) { w = t / groups_w; local = t % groups_w; Rw = R; row_groups = g.B / kChain; lj_col = R / kChain; }
     else { local = t - main_total; w = g.W - 1u; Rw = Rt; row_groups = Rt * (C / kChain); lj_col = col_t; }
-    const bool live = t < main_total + groups_t;
+    Rc8Job j;
+    j.live = t < main_total + groups_t;
     const bool is_row = local < row_groups;
-    const uint32_t lj = is_row ? C / kChain : lj_col;                   // groups per job
-    const uint32_t nbj = is_row ? C : Rw, chain = nbj / lj;
-    const uint32_t l2 = is_row ? local : local - row_groups, job = l2 / lj, sub = l2 % lj;
-    const uint32_t first = w * g.B + (is_row ? job * C + sub : sub * C + job);
-    const uint32_t step = is_row ? lj : lj * C;
-    auto fetch = [&](uint32_t i) {
-        const uint32_t b = first + i * step, t0 = taskoff[b], t1 = taskoff[b + 1];
-        return t1 > t0 ? load_pt2l(&partial[t0], x.q) : xyzzk_inf<1>();  // multi-task buckets were folded into slot t0
-    };
+    j.lj = is_row ? C / kChain : lj_col;                       // groups per job
+    j.chain = (is_row ? C : Rw) / j.lj;                        // buckets per group
+    const uint32_t l2 = is_row ? local : local - row_groups, job = l2 / j.lj;
+    j.sub = l2 % j.lj;
+    // row job: buckets C job + (sub + i lj);   column job: buckets C (sub + i lj) + job
+    j.first = w * g.B + (is_row ? job * C + j.sub : j.sub * C + job);
+    j.step = is_row ? j.lj : j.lj * C;
+    j.out = w * (R + C) + (is_row ? job : Rw + job);
+    return j;
+}
+__global__ void __launch_bounds__(256, 2)
+k_msm_rowcol8_p(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, RcpGeom g, Pt2L *__restrict__ rc) {
+    const int lane = threadIdx.x & 63, sl = lane & 7;
+    const DevLanes8 x{sl >> 1, sl & 1};
+    const uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 3;          // group
     XyzzK<1> acc = xyzzk_inf<1>();
-    if (live) {                                                         // uniform in the group
-        acc = fetch(0);
+    {
+        const Rc8Job j = rc8_job(t, g);
+        if (j.live) {                                                   // uniform in the group
 #pragma unroll 1
-        for (uint32_t i = 1; i < chain; i++) acc = add8k(x, acc, fetch(i));      // (no prefetch: the next point's 52 registers are the difference
-    }                                                                            //  between two waves per SIMD and spills; the other wave hides the load)
-    for (uint32_t off = (C / kChain) >> 1; off >= 1; off >>= 1) {       // a job's groups are one aligned run of the wave
-        const XyzzK<1> o = shfl_from(acc, (lane + 8 * (int)off) & 63);
-        if (live && off < lj && sub < off) acc = add8k(x, acc, o);
+            for (uint32_t i = 0; i < j.chain; i++) {                    // (no prefetch: the next point's 52 registers are the difference between
+                const uint32_t b = j.first + i * j.step, t0 = taskoff[b], t1 = taskoff[b + 1];      //  two waves per SIMD and spills)
+                if (t1 > t0) acc = add8k(x, acc, load_pt2l(&partial[t0], x.q));                     // multi-task buckets were folded into slot t0
+            }
+        }
     }
-    if (live && sub == 0 && sl < 2) store_pt2l(&rc[w * (R + C) + (is_row ? job : Rw + job)], acc, x.q);
+    const uint32_t C = 1u << g.logC;
+#pragma unroll 1
+    for (uint32_t off = (C / 16u) >> 1; off >= 1; off >>= 1) {          // a job's groups are one aligned run of the wave
+        const XyzzK<1> o = shfl_from(acc, (lane + 8 * (int)off) & 63);
+        const Rc8Job j = rc8_job(t, g);
+        if (j.live && off < j.lj && j.sub < off) acc = add8k(x, acc, o);
+    }
+    const Rc8Job j = rc8_job(t, g);
+    if (j.live && j.sub == 0 && sl < 2) store_pt2l(&rc[j.out], acc, x.q);
 }
 // grid = 2 W blocks: block 2 w sums hi Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of window w; 32 eight-lane groups, two entries each
 __global__ void __launch_bounds__(256)
