@@ -1749,16 +1749,20 @@ k_msm_reduce_rc_p(const Xyzz<FpL> *__restrict__ rc, RcpGeom g, Xyzz<Fp> *__restr
 // k_msm_reduce_rc8_p one block per (window, kind): group j takes the entries 2 j, 2 j + 1 as  (2 j + kind) (E0 + E1) + E1, then the block tree,
 // and leaves the canonical point the host reads (two per window).
 struct Rc8Job { uint32_t first, step, chain, lj, sub, out; bool live; };
+// groups of a window / of the top window in k_msm_rowcol8_p: rows R (C / kChain) + columns C max(1, R / kChain)
+__host__ __device__ inline uint32_t rc8_groups(const RcpGeom &g, uint32_t kChain, bool top) {
+    const uint32_t C = 1u << g.logC, R = (top ? g.BT : g.B) >> g.logC;
+    return R * (C / kChain) + C * (R >= kChain ? R / kChain : 1u);
+}
 // group t of k_msm_rowcol8_p -> its chain of buckets and, for the job's first group, the slot of the sum (computed twice -- before the chain
 // and again for the store -- so that none of it stays in registers across the additions: the kernel sits at the 256-register line)
-__device__ __forceinline__ Rc8Job rc8_job(uint32_t t, const RcpGeom &g) {
-    constexpr uint32_t kChain = 16;
+template <uint32_t kChain> __device__ __forceinline__ Rc8Job rc8_job(uint32_t t, const RcpGeom &g) {
     const uint32_t C = 1u << g.logC, R = g.B >> g.logC, Rt = g.BT >> g.logC;
-    const uint32_t col_t = Rt >= kChain ? Rt / kChain : 1u;
-    const uint32_t groups_w = 2u * g.B / kChain, groups_t = Rt * (C / kChain) + C * col_t, main_total = (g.W - 1u) * groups_w;
-    uint32_t w, local, Rw, row_groups, lj_col;
-    if (t < main_total) { w = t / groups_w; local = t % groups_w; Rw = R; row_groups = g.B / kChain; lj_col = R / kChain; }
-    else { local = t - main_total; w = g.W - 1u; Rw = Rt; row_groups = Rt * (C / kChain); lj_col = col_t; }
+    const uint32_t groups_w = rc8_groups(g, kChain, false), groups_t = rc8_groups(g, kChain, true), main_total = (g.W - 1u) * groups_w;
+    uint32_t w, local, Rw;
+    if (t < main_total) { w = t / groups_w; local = t % groups_w; Rw = R; }
+    else { local = t - main_total; w = g.W - 1u; Rw = Rt; }
+    const uint32_t row_groups = Rw * (C / kChain), lj_col = Rw >= kChain ? Rw / kChain : 1u;
     Rc8Job j;
     j.live = t < main_total + groups_t;
     const bool is_row = local < row_groups;
@@ -1772,6 +1776,7 @@ __device__ __forceinline__ Rc8Job rc8_job(uint32_t t, const RcpGeom &g) {
     j.out = w * (R + C) + (is_row ? job : Rw + job);
     return j;
 }
+template <uint32_t kChain>
 __global__ void __launch_bounds__(256, 2)
 k_msm_rowcol8_p(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ taskoff, RcpGeom g, Pt2L *__restrict__ rc) {
     const int lane = threadIdx.x & 63, sl = lane & 7;
@@ -1779,7 +1784,7 @@ k_msm_rowcol8_p(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ t
     const uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 3;          // group
     XyzzK<1> acc = xyzzk_inf<1>();
     {
-        const Rc8Job j = rc8_job(t, g);
+        const Rc8Job j = rc8_job<kChain>(t, g);
         if (j.live) {                                                   // uniform in the group
 #pragma unroll 1
             for (uint32_t i = 0; i < j.chain; i++) {                    // (no prefetch: the next point's 52 registers are the difference between
@@ -1790,12 +1795,12 @@ k_msm_rowcol8_p(const Pt2L *__restrict__ partial, const uint32_t *__restrict__ t
     }
     const uint32_t C = 1u << g.logC;
 #pragma unroll 1
-    for (uint32_t off = (C / 16u) >> 1; off >= 1; off >>= 1) {          // a job's groups are one aligned run of the wave
+    for (uint32_t off = (C / kChain) >> 1; off >= 1; off >>= 1) {       // a job's groups are one aligned run of the wave (column jobs: at most as many)
         const XyzzK<1> o = shfl_from(acc, (lane + 8 * (int)off) & 63);
-        const Rc8Job j = rc8_job(t, g);
+        const Rc8Job j = rc8_job<kChain>(t, g);
         if (j.live && off < j.lj && j.sub < off) acc = add8k(x, acc, o);
     }
-    const Rc8Job j = rc8_job(t, g);
+    const Rc8Job j = rc8_job<kChain>(t, g);
     if (j.live && j.sub == 0 && sl < 2) store_pt2l(&rc[j.out], acc, x.q);
 }
 // grid = 2 W blocks: block 2 w sums hi Row_hi, block 2 w + 1 sums (lo + 1) Col_lo of window w; 32 eight-lane groups, two entries each
@@ -1867,9 +1872,13 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool li
     if (rcp) {                  // c = 13: row / column sums, then the weighted sums (two launches; red_blocks = 2 W)
         // EIP2537_RCP_CHAIN=4: one lane per chain of 4 buckets (k_msm_rowcol_p); 8 | 16: a 4-lane group per chain (k_msm_rowcol_p4)
         static const uint32_t env_chain = [] { const char *v = getenv("EIP2537_RCP_CHAIN"); return v ? (uint32_t)atoi(v) : 0u; }();
-        const uint32_t chain = env_chain == 4u || env_chain == 8u || env_chain == 16u ? env_chain : 8u;
         const uint32_t C = 1u << rcp->logC, Rt = rcp->BT >> rcp->logC;
-        if (chain == 4u) {
+        const bool small = C < 64u;                         // the c = 8 plans (8 x 16 buckets per window): 4-lane groups per chain of 4
+        const uint32_t chain = small ? 0u : env_chain == 4u || env_chain == 8u || env_chain == 16u ? env_chain : 8u;
+        if (small) {
+            const uint32_t groups = (rcp->W - 1u) * (2u * rcp->B / 4u) + Rt * (C / 4u) + C * (Rt / 4u);
+            hipLaunchKernelGGL(k_msm_rowcol_p4<4u>, dim3((groups * 4u + 255u) / 256u), dim3(256), 0, s, partial, taskoff, *rcp, rc);
+        } else if (chain == 4u) {
             const uint32_t lanes = (rcp->W - 1u) * (2u * rcp->B / kRcpChain) + 2u * rcp->BT / kRcpChain;
             hipLaunchKernelGGL(k_msm_rowcol_p, dim3((lanes + 255u) / 256u), dim3(256), 0, s, partial, taskoff, *rcp, rc);
         } else {
@@ -1889,10 +1898,14 @@ static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool four, bool li
 static void launch_reduce(hipStream_t s, uint32_t red_blocks, bool, bool limb, const Xyzz<Fp2> *partial, const uint32_t *taskoff,
                           const MsmPlan &pl, const ReduceGrid &rg, Xyzz<Fp2> *winout, const RcpGeom *rcp, Xyzz<FpL> *rc) {
     if (rcp) {                  // c = 13, limb form: row / column sums, then the weighted sums (red_blocks = 2 W canonical points)
-        const uint32_t C = 1u << rcp->logC, Rt = rcp->BT >> rcp->logC;
-        const uint32_t groups = (rcp->W - 1u) * (2u * rcp->B / 16u) + Rt * (C / 16u) + C;
         Pt2L *rc8 = reinterpret_cast<Pt2L *>(rc);
-        hipLaunchKernelGGL(k_msm_rowcol8_p, dim3((groups * 8u + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const Pt2L *>(partial), taskoff, *rcp, rc8);
+        if ((1u << rcp->logC) < 64u) {      // the c = 8 plans (8 x 16 buckets per window): chains of 4
+            const uint32_t groups = (rcp->W - 1u) * rc8_groups(*rcp, 4u, false) + rc8_groups(*rcp, 4u, true);
+            hipLaunchKernelGGL(k_msm_rowcol8_p<4u>, dim3((groups * 8u + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const Pt2L *>(partial), taskoff, *rcp, rc8);
+        } else {
+            const uint32_t groups = (rcp->W - 1u) * rc8_groups(*rcp, 16u, false) + rc8_groups(*rcp, 16u, true);
+            hipLaunchKernelGGL(k_msm_rowcol8_p<16u>, dim3((groups * 8u + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const Pt2L *>(partial), taskoff, *rcp, rc8);
+        }
         hipLaunchKernelGGL(k_msm_reduce_rc8_p, dim3(red_blocks), dim3(256), 0, s, (const Pt2L *)rc8, *rcp, winout);
         return;
     }
@@ -2039,13 +2052,17 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     // G1, c = 13 (8 193 .. 2^17 records): the same split for the chain-bound plans (k_msm_rowcol_p / k_msm_reduce_rc_p); EIP2537_REDUCE_RCP=0:
     // the 4-lane running-sum chain k_msm_reduce4
     static const bool env_rcp = [] { const char *v = getenv("EIP2537_REDUCE_RCP"); return !v || atoi(v) != 0; }();
-    const RcpGeom rcp{pl.B, pl.BT, 6u, (uint32_t)pl.W};
+    // geometries: c = 13 -- 4 096 = 64 x 64 buckets per window, top window 8 x 64; c = 8 (up to 2 048 records) -- 128 = 8 x 16, top window 16 x 16
+    const bool rcp_geom13 = pl.c == 13 && pl.B == 4096u && pl.BT == 512u, rcp_geom8 = pl.c == 8 && pl.B == 128u && pl.BT == 256u;
+    const RcpGeom rcp{pl.B, pl.BT, rcp_geom8 ? 4u : 6u, (uint32_t)pl.W};
     // G2: accumulate, fold and reduce in limb form too (k_msm_accum2c_l, g2_limb.h); EIP2537_G2_LIMB=0: the FpI kernels
     static const bool env_g2limb = [] { const char *v = getenv("EIP2537_G2_LIMB"); return !v || atoi(v) != 0; }();
     const bool g2_limb = ReduceCfg<F>::kFourLane && env_g2limb;
     // G2, c = 13: k_msm_rowcol8_p / k_msm_reduce_rc8_p; EIP2537_REDUCE_RCP8=0: the running-sum chain k_msm_reduce8c_l
     static const bool env_rcp8 = [] { const char *v = getenv("EIP2537_REDUCE_RCP8"); return !v || atoi(v) != 0; }();
-    const bool two_level_p = !two_level && pl.c == 13 && pl.B == 4096u && pl.BT == 512u &&
+    // (G2 at c = 8: the device pipeline gains 65 us and the host loses 90 -- twice the window sums to add, at ~1 us per G2 addition, and
+    //  twice the vector conversions of the doubling chains -- so only G1 takes the small geometry: profiles/r04_reduce_rcp.txt)
+    const bool two_level_p = !two_level && (rcp_geom13 || (rcp_geom8 && !ReduceCfg<F>::kFourLane)) &&
                              (ReduceCfg<F>::kFourLane ? (g2_limb && env_rcp8) : (limb_form && four && env_rcp));
     if (two_level_p) red_blocks = 2u * (uint32_t)pl.W;
     const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level && !two_level_p;      // G2: one sum per window comes back, not one per block
@@ -2119,7 +2136,10 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     HIPCHK(e->scan_blk.reserve(dup * kScanBlkWords * 4));   // scan block totals, task-length histograms / offsets (two sets), slot ranges, window totals / bases
     HIPCHK(e->perm.reserve(dup * (size_t)pl.max_tasks * 4));
     HIPCHK(e->split_lists.reserve(dup * (size_t)pl.NB * 8));      // split-bucket lists: small | big
-    if (two_level_p) HIPCHK(e->rcsum.reserve((size_t)pl.W * 128u * (g2_limb ? sizeof(Pt2L) : sizeof(Xyzz<FpL>))));      // per window: 64 row + 64 column sums
+    if (two_level_p) {          // per window R row + C column sums (the top window may have more rows than the others)
+        const size_t per_w = (size_t)(std::max(rcp.B, rcp.BT) >> rcp.logC) + ((size_t)1 << rcp.logC);
+        HIPCHK(e->rcsum.reserve((size_t)pl.W * per_w * (g2_limb ? sizeof(Pt2L) : sizeof(Xyzz<FpL>))));
+    }
     if (two_level) {
         HIPCHK(e->bacc.reserve((size_t)pl.NB * sizeof(Xyzz<FpL>)));
         HIPCHK(e->taskbkt.reserve(dup * (size_t)pl.max_tasks * 4));
