@@ -1,0 +1,6 @@
+export GPU_MAX_HW_QUEUES=16
+timeout -k 10 700 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout -k 10 200 python tools/fuzz_long.py --seconds 60 --threads 4 2>&1 | tail -1
+for wl in "g1msm 7" "g2msm 7" "g1msm 10" "g2msm 10"; do set -- $wl
+python bench.py --workload $1 --log2n $2 --steps 30 --warmup 3 --no-cpu-baseline --no-secondary --no-host-abi --sustained 0 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$1 2^$2', 'ms/step %.3f'%d['ms_per_step'], 'pipeline %.3f'%d['roofline']['device_pipeline_ms'], d['bit_exact_vs_golden'])"; done
