@@ -92,8 +92,9 @@ static int msm_measured_width(uint32_t n, bool g2) {
     // round 2 re-sweep with the current kernels (profiles/r02_window_sweep.txt): c = 11 takes the band
     // between the small and the mid plans (G1 2^12: 0.83 against 0.90 ms; G2 2^12: 1.64 against 1.93 ms),
     // and G2 keeps c = 13 up to 2^18 records (5.7 against 6.0 ms for the work model's choice)
+    // round 4: with the two-level reduces of the c = 8 (G1) and c = 13 plans the c = 11 band (2 049 .. 8 192 records) is gone -- G1 2^12
+    // 0.62 -> 0.56 ms, 2^13 0.655 -> 0.574; G2 2^13 1.07 -> 1.03 (profiles/r04_window_sweep.txt, last section)
     if (n <= 2048) return 8;
-    if (n <= 8192) return 11;
     if (g2) return n <= (1u << 18) ? 13 : 0;      // larger G2 inputs: not measured, use the model
     return n <= (1u << 17) ? 13 : 16;
 }
