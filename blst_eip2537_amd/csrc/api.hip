@@ -629,11 +629,12 @@ template <class F> static int msm_coalesced(byte *out, const byte *in, size_t n)
     if (req.have_whole) {
         acc = req.whole;
     } else {                            // Horner over the 32 window sums, highest window first
-        acc = xyzz_inf<F>();
+        HornerAcc<F> h;
         for (int w = kMsmBatchWindows - 1; w >= 0; w--) {
-            horner_double_n(acc, kMsmBatchWindowBits);
-            acc = add(acc, req.wins[w]);
+            h.dbl_n(kMsmBatchWindowBits);
+            h.add(req.wins[w]);
         }
+        acc = h.result();
     }
     host_encode_point<F>(out, to_affine(acc));
     return E_SUCCESS;

@@ -2061,9 +2061,9 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     const bool g2_limb = ReduceCfg<F>::kFourLane && env_g2limb;
     // G2, c = 13: k_msm_rowcol8_p / k_msm_reduce_rc8_p; EIP2537_REDUCE_RCP8=0: the running-sum chain k_msm_reduce8c_l
     static const bool env_rcp8 = [] { const char *v = getenv("EIP2537_REDUCE_RCP8"); return !v || atoi(v) != 0; }();
-    // (G2 at c = 8: the device pipeline gains 65 us and the host loses 90 -- twice the window sums to add, at ~1 us per G2 addition, and
-    //  twice the vector conversions of the doubling chains -- so only G1 takes the small geometry: profiles/r04_reduce_rcp.txt)
-    const bool two_level_p = !two_level && (rcp_geom13 || (rcp_geom8 && !ReduceCfg<F>::kFourLane)) &&
+    // (G2 at c = 8 lost 30 us per call while the host added its twice-as-many window sums in scalar code; with the Horner accumulator kept
+    //  in one IFMA vector, additions included, it gains: profiles/r04_reduce_rcp.txt)
+    const bool two_level_p = !two_level && (rcp_geom13 || rcp_geom8) &&
                              (ReduceCfg<F>::kFourLane ? (g2_limb && env_rcp8) : (limb_form && four && env_rcp));
     if (two_level_p) red_blocks = 2u * (uint32_t)pl.W;
     const bool dev_winsum = window_sums_on_device((const F *)nullptr) && !two_level && !two_level_p;      // G2: one sum per window comes back, not one per block
@@ -2318,8 +2318,8 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
     if (hipEventElapsedTime(&ms, e->ev_b, e->ev_stop) == hipSuccess) e->last_aux_ms[1] = ms;      // fold + bucket reduce
     if (herr != ~0ull) return (int)(herr & 7ull);
 
-    // Horner over windows on the host (W * c doublings + a handful of additions)
-    Xyzz<F> acc = xyzz_inf<F>();
+    // Horner over windows on the host (W * c doublings + a handful of additions); G2: the accumulator stays in one IFMA vector (ifma_horner.h)
+    HornerAcc<F> h;
     if (two_level) {
         // window sum = 256 R_w + C_w: two half-windows of 8 bits each (C_w arrives as its lower and upper columns); the top window is its
         // two halves added
@@ -2327,29 +2327,30 @@ static int msm_device_t(Engine *e, const void *d_in, size_t n, uint32_t *partial
         hw[3 * (size_t)(pl.W - 1)] = add(hw[3 * (size_t)(pl.W - 1)], hw[3 * (size_t)pl.W]);
         hw[3 * (size_t)(pl.W - 1) + 1] = add(hw[3 * (size_t)(pl.W - 1) + 1], hw[3 * (size_t)pl.W + 1]);
         for (int w = pl.W - 1; w >= 0; w--)
-            for (int h = 0; h < 2; h++) {
-                horner_double_n(acc, pl.c / 2);
-                acc = add(acc, hw[3 * w + h]);
+            for (int hf = 0; hf < 2; hf++) {
+                h.dbl_n(pl.c / 2);
+                h.add(hw[3 * w + hf]);
             }
     } else if (two_level_p) {
         // window sum = 64 R_w + C_w: a 7-bit and a 6-bit half-window
         for (int w = pl.W - 1; w >= 0; w--) {
-            horner_double_n(acc, pl.c - (int)rcp.logC);
-            acc = add(acc, hw[2 * (size_t)w]);
-            horner_double_n(acc, (int)rcp.logC);
-            acc = add(acc, hw[2 * (size_t)w + 1]);
+            h.dbl_n(pl.c - (int)rcp.logC);
+            h.add(hw[2 * (size_t)w]);
+            h.dbl_n((int)rcp.logC);
+            h.add(hw[2 * (size_t)w + 1]);
         }
     } else if (dev_winsum) {
         for (int w = pl.W - 1; w >= 0; w--) {
-            horner_double_n(acc, pl.c);
-            acc = add(acc, hw[(size_t)w]);
+            h.dbl_n(pl.c);
+            h.add(hw[(size_t)w]);
         }
     } else
     for (int w = pl.W - 1; w >= 0; w--) {
-        horner_double_n(acc, pl.c);
+        h.dbl_n(pl.c);
         const uint32_t nb = w == pl.W - 1 ? rg.bt : rg.bn, b0 = (uint32_t)w * rg.bn;
-        for (uint32_t b = 0; b < nb; b++) acc = add(acc, hw[b0 + b]);
+        for (uint32_t b = 0; b < nb; b++) h.add(hw[b0 + b]);
     }
+    const Xyzz<F> acc = h.result();
     memcpy(partial_words, &acc, sizeof acc);
     return E_SUCCESS;
 }

@@ -137,6 +137,34 @@ __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl,avx512bw"))) static 
                 if (!same1(a1, b1) || !same2(a2, b2)) bad5++;
             }
         }
+        // the vector Horner accumulator (G2Horner: doubling chains AND additions in one vector) against the scalar pass, with window
+        // sums that are infinity, equal to the accumulator (doubling case) and opposite to it (cancellation)
+        for (int it = 0; it < 60; it++) {
+            uint32_t k[8];
+            for (auto &w : k) w = (uint32_t)rnd();
+            const Xyzz<Fp2> p2 = scalar_mul(g2, k, 256);
+            const Aff<Fp2> c2 = map_to_curve<Fp2>(r2());
+            const Xyzz<Fp2> q2{c2.x, c2.y, fp2_one(), fp2_one()};
+            Xyzz<Fp2> a = xyzz_inf<Fp2>();
+            HornerAcc<Fp2> hv;
+            for (int w = 0; w < 24; w++) {
+                const int n = 1 + (int)(rnd() % 13);
+                for (int i = 0; i < n; i++) a = dbl(a);
+                hv.dbl_n(n);
+                Xyzz<Fp2> term = (w % 3 == 0) ? p2 : q2;
+                const int kind = (it + w) % 7;
+                if (kind == 1) term = xyzz_inf<Fp2>();
+                if (kind == 2 && !is_zero(a.zz)) term = a;                                   // P + P
+                if (kind == 3 && !is_zero(a.zz)) term = Xyzz<Fp2>{a.x, neg(a.y), a.zz, a.zzz};  // P - P
+                if (kind == 4 && !is_zero(a.zz)) {                                            // the same point in another representative
+                    const Fp2 l = r2(), ll = sqr(l), lll = mul(ll, l);
+                    term = Xyzz<Fp2>{mul(a.x, ll), mul(a.y, lll), mul(a.zz, ll), mul(a.zzz, lll)};
+                }
+                a = add(a, term);
+                hv.add(term);
+                if (!same2(hv.result(), a)) { bad5++; break; }
+            }
+        }
         Xyzz<Fp2> i2 = xyzz_inf<Fp2>();
         double_n(i2, 5);                                       // infinity stays infinity through the vectors too
         if (!is_zero(i2.zz)) bad5++;
